@@ -1,0 +1,175 @@
+/*
+ * qvc.h -- C ABI of the MI355X-native QuickVC inference hot path (libqvc_hip.so).
+ *
+ * This is the drop-in boundary for the path SynthesizerTrn.infer =
+ *   enc_p (WN) -> reverse ResidualCouplingBlock -> multi-stream iSTFT generator
+ * of tarepan/QuickVC-official.  The reference has no native code; its "FFI" for
+ * this path is the Python surface of models.py.  Each entry point below names the
+ * reference interface (file:line under the reference checkout) it replaces.  The
+ * Python host (quickvc-official_amd/engine.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types.
+ *   - every function returns an int status: 0 = QVC_OK, negative = error
+ *     (qvc_status_string() names it).  Nothing throws, aborts or prints.
+ *   - device pointers are raw HIP device addresses owned by the caller
+ *     (tensor.data_ptr()); the library allocates nothing and keeps no global state.
+ *   - all device work is enqueued asynchronously on the caller's hipStream_t
+ *     (passed as void*); no host sync, no allocation, no host read inside, so
+ *     every call is hipGraph-capturable.  Thread-safe by statelessness.
+ *   - every entry point that needs scratch has a *_workspace_bytes() query.
+ *
+ * Layouts
+ *   External tensors keep the reference's (B, C, T) contiguous fp32 layout.
+ *   Internal activations are "frame-major": [B][T][C] (channel innermost), so that
+ *   the 8 consecutive channels one MFMA lane consumes are one 16-byte access.
+ */
+#ifndef QVC_H
+#define QVC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QVC_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  QVC_OK = 0,
+  QVC_ERR_BAD_ARG = -1,        /* null pointer, non-positive size, bad enum          */
+  QVC_ERR_BAD_CONFIG = -2,     /* unsupported hyper-parameters                        */
+  QVC_ERR_MISSING_TENSOR = -3, /* a state-dict entry the path needs is absent         */
+  QVC_ERR_BAD_SHAPE = -4,      /* a tensor has an unexpected shape                    */
+  QVC_ERR_SMALL_BUFFER = -5,   /* blob / workspace smaller than *_bytes() says        */
+  QVC_ERR_LAUNCH = -6,         /* hipLaunchKernel / hipGetLastError reported failure  */
+  QVC_ERR_NO_DEVICE = -7       /* no HIP device / wrong architecture                  */
+};
+
+/* ---- decoder variants (models.py:588) ----------------------------------- */
+enum {
+  QVC_DEC_ISTFT = 0,       /* iSTFT_Generator            models.py:98-192  (subbands = 1, no band synthesis) */
+  QVC_DEC_MULTIBAND = 1,   /* Multiband_iSTFT_Generator  models.py:195-301 (fixed PQMF, pqmf.py:106-117)     */
+  QVC_DEC_MULTISTREAM = 2  /* Multistream_iSTFT_Generator models.py:304-415 (learned 63-tap FIR) -- shipped  */
+};
+
+/* ---- MFMA operand types -------------------------------------------------- */
+enum {
+  QVC_BF16 = 0,  /* bf16 operands, fp32 accumulate (BASELINE.json configs 2-5) */
+  QVC_F16 = 1    /* fp16 operands, fp32 accumulate (same MFMA rate, 3 more mantissa bits) */
+};
+
+#define QVC_MAX_UPS 4
+#define QVC_MAX_RESBLOCKS 4
+
+/*
+ * Hyper-parameters of SynthesizerTrn (models.py:551-591) that shape the path.
+ * Filled by the host from the reference's JSON "model" section.
+ */
+typedef struct qvc_config {
+  int32_t unit_channels;            /* 256, hard-coded at models.py:579                 */
+  int32_t inter_channels;           /* latent z channels                                 */
+  int32_t hidden_channels;          /* WN width                                          */
+  int32_t gin_channels;             /* speaker embedding size                            */
+  int32_t wn_kernel_size;           /* 5  (models.py:582-584)                            */
+  int32_t enc_layers;               /* 16 (models.py:583)                                */
+  int32_t flow_layers;              /* 4  WN layers per coupling layer (models.py:584)   */
+  int32_t n_flows;                  /* 4                                                  */
+  int32_t upsample_initial_channel; /* 512                                               */
+  int32_t n_ups;                    /* len(upsample_rates)                               */
+  int32_t upsample_rates[QVC_MAX_UPS];
+  int32_t upsample_kernel_sizes[QVC_MAX_UPS];
+  int32_t n_resblocks;              /* len(resblock_kernel_sizes)                        */
+  int32_t resblock_kernel_sizes[QVC_MAX_RESBLOCKS];
+  int32_t resblock_dilations[QVC_MAX_RESBLOCKS][3];
+  int32_t n_fft;                    /* gen_istft_n_fft  (16)                             */
+  int32_t hop;                      /* gen_istft_hop_size (4)                            */
+  int32_t subbands;                 /* 4 (1 for QVC_DEC_ISTFT)                           */
+  int32_t decoder;                  /* QVC_DEC_*                                         */
+  int32_t fir_taps;                 /* 63: multistream_conv_post / PQMF taps+1           */
+  int32_t operand_dtype;            /* QVC_BF16 / QVC_F16                                */
+  int32_t precise_post;             /* 1: conv_post with split (hi+lo) operands          */
+} qvc_config;
+
+/* One named fp32 tensor of the reference checkpoint's state_dict (utils.py:183-193). */
+typedef struct qvc_tensor {
+  const char* name;    /* e.g. "enc_p.enc.in_layers.3.weight_v"  */
+  const float* data;   /* host pointer, contiguous fp32           */
+  int32_t ndim;
+  int64_t shape[4];
+} qvc_tensor;
+
+/* ---- library info ---------------------------------------------------------- */
+int qvc_abi_version(void);
+const char* qvc_status_string(int status);
+/* 0 when a gfx950 device is visible to this process, QVC_ERR_NO_DEVICE otherwise. */
+int qvc_device_check(void);
+
+/* ---- weights: replaces nn.Module.load_state_dict + per-forward weight_norm ----
+ * Reference: utils.py:148-180 (load), modules.py:54,64,67,134-143 and
+ * models.py:327,333,346,357 (weight_norm recomputed every forward).  Folds
+ * w = g*v/||v|| once, folds the four channel Flips (modules.py:165-170) into the
+ * coupling layers' weight layout, rewrites ConvTranspose1d as polyphase filters,
+ * converts to the MFMA operand type and lays everything out as per-wave
+ * fragment streams.  Pure host code.
+ */
+int64_t qvc_blob_bytes(const qvc_config* cfg);
+int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors, int32_t n_tensors,
+                     void* blob_host, int64_t blob_bytes);
+
+/* ---- whole path: replaces SynthesizerTrn.infer after the speaker encoder ------
+ * Reference: models.py:638-642 (z_p = enc_p(unit); z = flow(z_p, g, reverse);
+ * o = dec(z, g)), generalised to a batch of utterances with per-utterance g.
+ *   unit  (B, unit_channels, T) fp32   HuBERT-soft units          (convert.py:79)
+ *   g     (B, gin_channels)     fp32   speaker embeddings          (models.py:635)
+ *   noise (B, inter_channels, T) fp32  the N(0,1) draw of models.py:94
+ *   out   (B, T*prod(ups)*hop*subbands) fp32 waveform = (B,1,320*T)
+ */
+int64_t qvc_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t frames);
+int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev,
+                    const float* unit, const float* g, const float* noise, float* out,
+                    int32_t batch, int32_t frames,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- stages (same workspace; for stage-level parity tests and profiling) ------
+ * Frame-major fp32 tensors: z_p / z are [B][T][inter_channels].
+ */
+/* CondNormalWN.forward (enc_p), models.py:75-95: unit, noise -> z_p. */
+int qvc_enc_p(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* noise,
+              float* z_p_fm, int32_t batch, int32_t frames,
+              void* workspace, int64_t workspace_bytes, void* stream);
+/* ResidualCouplingBlock.forward(reverse=True), models.py:39-51: in place on z. */
+int qvc_flow_reverse(const qvc_config* cfg, const void* blob_dev, float* z_fm, const float* g,
+                     int32_t batch, int32_t frames,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+/* Generator trunk, models.py:372-390: z -> subband_conv_post output [B][F][subbands*2*(n_fft/2+1)],
+ * F = frames*prod(ups)+1 (the ReflectionPad1d((1,0)) adds one frame). */
+int qvc_dec_trunk(const qvc_config* cfg, const void* blob_dev, const float* z_fm, const float* g,
+                  float* post_fm, int32_t batch, int32_t frames,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+/* exp / pi*sin / per-band iSTFT / zero-stuff / synthesis FIR, models.py:394-406 and
+ * pqmf.py:106-117: post_fm [B][F][...] -> out (B, subbands*hop*(F-1)); y_mb (optional,
+ * may be NULL) receives the sub-band signals (B, subbands, hop*(F-1)). */
+int qvc_istft_synth(const qvc_config* cfg, const void* blob_dev, const float* post_fm,
+                    float* out, float* y_mb, int32_t batch, int32_t post_frames, void* stream);
+
+/* ---- one conv through the MFMA kernel (unit tests of the kernel itself) ---------
+ * y[b,co,t] = bias[co] + sum_{ci,j} w[co,ci,j] * lrelu(x[b,ci,t+(j-(k-1)/2)*dil], slope_in)
+ * x, y are (B,C,T) fp32; w is (Cout,Cin,k) fp32 on the HOST (packed internally into
+ * w_scratch_host, then copied to w_scratch_dev on the stream).  Replaces
+ * torch.nn.functional.conv1d as used at modules.py:91,104,150-153.
+ */
+int64_t qvc_conv1d_scratch_bytes(int32_t cout, int32_t cin, int32_t k);
+int64_t qvc_conv1d_workspace_bytes(int32_t batch, int32_t cout, int32_t cin, int32_t frames);
+int qvc_conv1d(const float* x, const float* w_host, const float* bias_host, float* y,
+               int32_t batch, int32_t cin, int32_t cout, int32_t frames,
+               int32_t k, int32_t dilation, float slope_in, int32_t operand_dtype,
+               void* w_scratch_host, void* w_scratch_dev, int64_t scratch_bytes,
+               void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QVC_H */

@@ -1,0 +1,78 @@
+"""The CPU oracle against the golden vectors recorded from the reference.
+
+Inputs and weights are regenerated from the seeds in tests/golden/manifest.json; the
+fixtures hold what the *reference* produced (tests/golden/make_golden.py).  Tolerance:
+2e-5 * max(1, |tap|_max) absolute -- fp32 re-association noise only.
+"""
+import numpy as np
+import pytest
+import torch
+
+import qvc_oracle as oracle
+from helpers import load_case, regenerate, subsample, manifest
+
+CASES = [n for n in manifest() if n != "mini_spk"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_taps(name):
+    entry, gold = load_case(name)
+    _model, sd, unit, g, noise = regenerate(entry)
+    taps = {}
+    o = oracle.infer_from_g(sd, entry["config"], unit, g.unsqueeze(-1), noise, taps)
+    taps["o"] = o
+    taps["enc_p.enc.out"] = taps["enc_p.enc.layer15.out"]
+    assert o.shape == (entry["batch"], 1, 320 * entry["frames"])            # output length rule, SURVEY 4
+    for tap in entry["taps"]:
+        got = taps[tap]
+        assert tuple(got.shape) == tuple(gold[tap + "::shape"]), tap
+        limit = entry["subsample_limit"] if tap != "o" else 1 << 30
+        want = gold[tap]
+        have = subsample(got, limit)
+        tol = 2e-5 * max(1.0, float(np.abs(want).max()))
+        assert np.abs(have - want).max() <= tol, f"{name}:{tap}"
+        # whole-tensor energy (catches errors the strided subsample would miss)
+        assert float(got.double().pow(2).sum()) == pytest.approx(float(gold[tap + "::sumsq"][0]), rel=1e-4)
+
+
+def test_speaker_encoder_and_infer_api():
+    """SpeakerEncoder.embed_utterance (models.py:528-546) incl. the <=128-frame branch, and batch-1 infer()."""
+    from quickvc_official_amd.synth import make_synthetic_mel
+    entry, _ = load_case("mini")
+    spk = dict(np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "mini_spk.npz")))
+    model, sd, unit, g, noise = regenerate(entry)
+    sdf = {k: v.float() for k, v in sd.items()}
+    for frames in (100, 128, 300):
+        mel = make_synthetic_mel(frames, 80, seed=7 + frames)
+        e = oracle.speaker_embed_utterance(sdf, mel.transpose(1, 2))
+        assert np.abs(e.numpy() - spk[f"g_{frames}"]).max() < 1e-6
+        # the product's own PyTorch speaker encoder (host code) must agree as well
+        model.load_state_dict(sd)
+        e2 = model.enc_spk.embed_utterance(mel.transpose(1, 2))
+        assert np.abs(e2.numpy() - spk[f"g_{frames}"]).max() < 1e-6
+    mel = make_synthetic_mel(300, 80, seed=307)
+    o = oracle.infer(sd, entry["config"], unit[:1], mel, noise[:1])
+    assert np.abs(o.numpy() - spk["infer_o"]).max() < 2e-5
+
+
+def test_istft_closed_form_equals_torch_istft():
+    """The explicit OLA of the oracle == torch.istft semantics the reference relies on (models.py:350,401)."""
+    torch.manual_seed(3)
+    for frames in (2, 5, 33):
+        s = torch.randn(3, 9, frames) * 0.5
+        p = torch.randn(3, 9, frames)
+        mine = oracle.istft_closed_form(s, p, 16, 4)
+        spec = torch.exp(s) * torch.exp(1j * (np.pi * torch.sin(p)))
+        ref = torch.istft(spec, 16, 4, 16, torch.hann_window(16), center=True, normalized=False, onesided=True)
+        assert mine.shape == ref.shape == (3, 4 * (frames - 1))
+        assert (mine - ref).abs().max() < 2e-6
+
+
+def test_weight_norm_fold_matches_torch():
+    torch.manual_seed(1)
+    for shape in [(6, 4, 5), (8, 3, 16)]:
+        conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(shape[1], shape[0], shape[2]))
+        conv.weight_g.data.mul_(torch.rand_like(conv.weight_g) + 0.5)
+        w = oracle.fold_weight_norm(conv.weight_v.data, conv.weight_g.data)
+        x = torch.randn(1, shape[1], 40)
+        assert torch.allclose(torch.nn.functional.conv1d(x, w, conv.bias), conv(x), atol=1e-6)
