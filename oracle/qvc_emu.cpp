@@ -1,0 +1,282 @@
+// qvc_emu.cpp -- TEST INFRASTRUCTURE: a CPU replay of the product's launch sequence.
+//
+// Built by __graft_entry__.build() into oracle/_build/libqvc_emu.so and loaded only by tests.
+// It instantiates the product's Path<> (quickvc-official_amd/csrc/qvc_path.h) with a backend whose
+// "kernels" are plain scalar loops that consume the SAME packed weight blob through the SAME
+// fragment index arithmetic as the gfx950 kernels, and that round operands to the MFMA operand
+// type at the same places.  Purpose: check on a machine without a GPU that the packer
+// (weight-norm fold, flip folding, polyphase rewrite, fragment order) and the orchestration
+// (buffers, strides, fused epilogues) reproduce the oracle, so that what is left to verify on
+// the MI355X is each kernel against this emulation's per-launch semantics.
+// The product library never links or calls this file.
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../quickvc-official_amd/csrc/qvc_path.h"
+
+namespace {
+using namespace qvc;
+
+float from_bf16(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+float from_f16(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const int exp = (h >> 10) & 0x1f;
+  const uint32_t man = h & 0x3ffu;
+  float v;
+  if (exp == 0) v = std::ldexp((float)man, -24);
+  else if (exp == 31) v = man ? NAN : INFINITY;
+  else v = std::ldexp((float)(man | 0x400u), exp - 25);
+  return sign ? -v : v;
+}
+uint16_t to_bf16(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+uint16_t to_f16(float f) {   // round-to-nearest-even, saturating (as the device conversion does)
+  if (std::isnan(f)) return 0x7e00;
+  float a = std::fabs(f);
+  uint16_t sign = std::signbit(f) ? 0x8000 : 0;
+  if (a >= 65520.f) return sign | 0x7bff;
+  if (a < 5.9604644775390625e-08f * 0.5f) return sign;
+  int e; float m = std::frexp(a, &e);          // a = m * 2^e, m in [0.5,1)
+  int exp = e - 1;                              // a = (2m) * 2^exp
+  if (exp < -14) {
+    float q = a / 5.9604644775390625e-08f;      // units of 2^-24
+    float r = std::nearbyint(q);
+    return sign | (uint16_t)r;
+  }
+  float q = (2.f * m - 1.f) * 1024.f;
+  float r = std::nearbyint(q);
+  uint32_t man = (uint32_t)r, ex = (uint32_t)(exp + 15);
+  if (man == 1024) { man = 0; ++ex; }
+  return sign | (uint16_t)((ex << 10) | man);
+}
+float round_op(float f, int dtype) {
+  if (dtype == QVC_F16) { f = std::fmin(std::fmax(f, -65504.f), 65504.f); return from_f16(to_f16(f)); }
+  return from_bf16(to_bf16(f));
+}
+float lrelu(float x, float s) { return x > 0.f ? x : x * s; }
+
+struct EmuBackend {
+  // ---- conv: dense weights are recovered from the fragment stream with the kernel's index math
+  int conv(const ConvDesc& d, const ConvArgs& a, int B, int epi, int dtype) {
+    const int KS = d.KS(), nIt = d.nIt(), MP = d.MP();
+    std::vector<float> W((size_t)MP * nIt * kKStep, 0.f);   // [packed row][it][32]
+    const uint16_t* src = static_cast<const uint16_t*>(a.w);
+    for (int chunk = 0; chunk < d.nchunk; ++chunk)
+      for (int wave = 0; wave < kWaves; ++wave)
+        for (int it = 0; it < nIt; ++it)
+          for (int mf = 0; mf < d.MF; ++mf)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const size_t frag = ((size_t)(chunk * kWaves + wave) * nIt + it) * d.MF + mf;
+                const uint16_t h = src[(frag * 64 + lane) * 8 + j];
+                const int prow = ((chunk * kWaves + wave) * d.MF + mf) * 16 + (lane & 15);
+                const int k = (lane >> 4) * 8 + j;
+                W[((size_t)prow * nIt + it) * kKStep + k] = dtype == QVC_F16 ? from_f16(h) : from_bf16(h);
+              }
+    const int R_halo = (d.taps - 1) * d.dil;
+    if (acc_store.size() < (size_t)MP * (size_t)a.Nq) acc_store.resize((size_t)MP * (size_t)a.Nq);
+    acc_ = acc_store.data();
+    for (int b = 0; b < B; ++b) {
+      // staged input, rounded like the LDS tile: rows t in [-left, Nq - left + halo)
+      const int rows = a.Nq + R_halo;
+      std::vector<float> X((size_t)rows * d.CinP, 0.f);
+      for (int r = 0; r < rows; ++r) {
+        const int ti = r - d.left;
+        for (int c = 0; c < d.Cin; ++c) {
+          float v = 0.f; bool ok;
+          if (a.x_kind == XK_F32_FM) {
+            int s;
+            if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; s = ti == 0 ? 1 : ti - 1; } else { ok = ti >= 0 && ti < a.T_in; s = ti; }
+            if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)s * a.x_ts + a.x_c0 + c], a.slope_in), dtype);
+          } else if (a.x_kind == XK_OP_FM) {
+            ok = ti >= 0 && ti < a.T_in;
+            if (ok) { uint16_t h = static_cast<const uint16_t*>(a.x)[(size_t)b * a.x_bs + (size_t)ti * a.x_ts + a.x_c0 + c]; v = dtype == QVC_F16 ? from_f16(h) : from_bf16(h); }
+          } else {
+            ok = ti >= 0 && ti < a.T_in;
+            if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)c * a.x_ts + ti], a.slope_in), dtype);
+          }
+          X[(size_t)r * d.CinP + c] = v;
+        }
+      }
+      for (int chunk = 0; chunk < d.nchunk; ++chunk)
+        for (int wave = 0; wave < kWaves; ++wave)
+          for (int mf = 0; mf < d.MF; ++mf)
+            for (int i = 0; i < 16; ++i) {
+              const int prow = ((chunk * kWaves + wave) * d.MF + mf) * 16 + i;
+              for (int q = 0; q < a.Nq; ++q) {
+                double acc = 0.0;
+                for (int it = 0; it < nIt; ++it) {
+                  const int tap = it / KS, ks = it % KS;
+                  const float* xr = &X[(size_t)(q + tap * d.dil) * d.CinP + ks * kKStep];
+                  const float* wr = &W[((size_t)prow * nIt + it) * kKStep];
+                  for (int k = 0; k < kKStep; ++k) acc += (double)wr[k] * xr[k];
+                }
+                acc_[idx(prow, q, a.Nq)] = (float)acc;
+              }
+            }
+      epilogue(d, a, b, epi, dtype);
+    }
+    return QVC_OK;
+  }
+  std::vector<float> acc_store;
+  float* acc_ = nullptr;
+  static size_t idx(int prow, int q, int Nq) { return (size_t)prow * Nq + q; }
+
+  void epilogue(const ConvDesc& d, const ConvArgs& a, int b, int epi, int dtype) {
+    auto store16 = [&](void* base, size_t off, float v) {
+      static_cast<uint16_t*>(base)[off] = dtype == QVC_F16 ? to_f16(std::fmin(std::fmax(v, -65504.f), 65504.f)) : to_bf16(v);
+    };
+    if (epi == EPI_GAU) {
+      const int H = a.gau_H;
+      for (int chunk = 0; chunk < d.nchunk; ++chunk)
+        for (int wave = 0; wave < kWaves; ++wave)
+          for (int i = 0; i < 16; ++i) {
+            const int ch = chunk * 64 + wave * 16 + i;
+            if (ch >= H) continue;
+            const int pt = ((chunk * kWaves + wave) * 2 + 0) * 16 + i, ps = ((chunk * kWaves + wave) * 2 + 1) * 16 + i;
+            const float* bb = a.bbias + (size_t)b * a.bbias_bs;
+            for (int q = 0; q < a.Nq; ++q) {
+              const float t = acc_[idx(pt, q, a.Nq)] + bb[ch], s = acc_[idx(ps, q, a.Nq)] + bb[H + ch];
+              const float act = std::tanh(t) * (1.f / (1.f + std::exp(-s)));
+              store16(a.y16, (size_t)b * a.y16_bs + (size_t)q * a.y16_ts + ch, act);
+            }
+          }
+      return;
+    }
+    for (int v = 0; v < d.M; ++v) {
+      const int ph = d.up_s > 1 ? v / d.Cout : 0, co = d.up_s > 1 ? v % d.Cout : v;
+      float bias = a.bias ? a.bias[v] : 0.f;
+      if (a.bbias) bias += a.bbias[(size_t)b * a.bbias_bs + v];
+      for (int q = 0; q < a.Nq; ++q) {
+        const int o = q * d.up_s + ph - d.up_p;
+        if (o < 0 || o >= a.T_out) continue;
+        float val = acc_[idx(v, q, a.Nq)] + bias;
+        if (a.y32b && v >= a.split) { a.y32b[(size_t)b * a.y32_bs + (size_t)o * a.y32_ts + (v - a.split)] += val; continue; }
+        if (a.res) val = a.res[(size_t)b * a.res_bs + (size_t)o * a.res_ts + a.res_c0 + co] + a.res_sign * val;
+        if (a.y32) {
+          float* p = a.y32 + (size_t)b * a.y32_bs + (size_t)o * a.y32_ts + a.y32_c0 + co;
+          *p = (a.y_accum ? *p : 0.f) + val * a.y_scale;
+        }
+        if (a.y16) store16(a.y16, (size_t)b * a.y16_bs + (size_t)o * a.y16_ts + co, lrelu(val, a.slope_out));
+      }
+    }
+  }
+
+  int gemv(const GemvArgs& a) {
+    for (int b = 0; b < a.batch; ++b)
+      for (int r = 0; r < a.rows; ++r) {
+        double s = 0.0;
+        for (int k = 0; k < a.gin; ++k) s += (double)a.w[(size_t)r * a.gin + k] * a.g[(size_t)b * a.gin + k];
+        a.out[(size_t)b * a.rows + r] = (float)s + a.bias[r];
+      }
+    return QVC_OK;
+  }
+  int sample(const SampleArgs& a) {
+    for (int b = 0; b < a.batch; ++b)
+      for (int t = 0; t < a.frames; ++t)
+        for (int c = 0; c < a.C; ++c) {
+          const size_t bt = (size_t)b * a.frames + t;
+          a.z[bt * a.C + c] = a.stats[bt * 2 * a.C + c] + a.noise[((size_t)b * a.C + c) * a.frames + t] * std::exp(a.stats[bt * 2 * a.C + a.C + c]);
+        }
+    return QVC_OK;
+  }
+  // Tail: same formulas as istft_synth_kernel, evaluated sample by sample.
+  int tail(const TailArgs& a) {
+    const int F = a.F, L = 4 * (F - 1), NO = 4 * L;
+    const double pi = 3.14159265358979323846;
+    std::vector<double> xw((size_t)4 * F * 16), y((size_t)4 * L);
+    for (int b = 0; b < a.batch; ++b) {
+      const float* pb = a.post + (size_t)b * F * 72;
+      for (int k = 0; k < 4; ++k)
+        for (int t = 0; t < F; ++t) {
+          double re[9], im[9];
+          for (int q = 0; q < 9; ++q) {
+            const double mag = std::exp((double)pb[(size_t)t * 72 + k * 18 + q]);
+            const double ph = pi * std::sin((double)pb[(size_t)t * 72 + k * 18 + 9 + q]);
+            re[q] = mag * std::cos(ph); im[q] = mag * std::sin(ph);
+          }
+          for (int m = 0; m < 16; ++m) {
+            double acc = re[0] + ((m & 1) ? -re[8] : re[8]);
+            for (int q = 1; q < 8; ++q) acc += 2.0 * (re[q] * std::cos(2 * pi * q * m / 16) - im[q] * std::sin(2 * pi * q * m / 16));
+            xw[((size_t)k * F + t) * 16 + m] = acc / 16.0 * (0.5 - 0.5 * std::cos(2 * pi * m / 16));
+          }
+        }
+      for (int k = 0; k < 4; ++k)
+        for (int n = 0; n < L; ++n) {
+          double num = 0, env = 0;
+          for (int t = 0; t < F; ++t) {
+            const int m = n + 8 - 4 * t;
+            if (m < 0 || m >= 16) continue;
+            const double w = 0.5 - 0.5 * std::cos(2 * pi * m / 16);
+            num += xw[((size_t)k * F + t) * 16 + m]; env += w * w;
+          }
+          y[(size_t)k * L + n] = num / env;
+          if (a.y_mb) a.y_mb[((size_t)b * 4 + k) * L + n] = (float)(num / env);
+        }
+      for (int o = 0; o < NO; ++o) {
+        double s = 0;
+        for (int k = 0; k < 4; ++k)
+          for (int j = 0; j < 63; ++j) {
+            const int u = o + j - 31;
+            if (u < 0 || u >= NO || (u & 3)) continue;
+            s += (double)a.fir[k * 63 + j] * y[(size_t)k * L + (u >> 2)];
+          }
+        a.out[(size_t)b * NO + o] = (float)s;
+      }
+    }
+    return QVC_OK;
+  }
+  int zero(void* p, size_t bytes) { std::memset(p, 0, bytes); return QVC_OK; }
+};
+
+struct Run {
+  Plan P; Workspace W; EmuBackend be;
+  int prepare(const qvc_config* cfg, int B, int T, int64_t ws_bytes) {
+    P = build_plan(*cfg);
+    if (P.status != QVC_OK) return P.status;
+    W = carve_workspace(P, B, T);
+    if (ws_bytes < W.bytes) return QVC_ERR_SMALL_BUFFER;
+    return QVC_OK;
+  }
+};
+}  // namespace
+
+extern "C" {
+
+// Same signature as qvc_infer_batch, host pointers everywhere, no stream.
+int qvc_emu_infer_batch(const qvc_config* cfg, const void* blob, const float* unit, const float* g, const float* noise,
+                        float* out, int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes) {
+  Run r;
+  int st = r.prepare(cfg, batch, frames, workspace_bytes);
+  if (st != QVC_OK) return st;
+  Path<EmuBackend> c{r.P, static_cast<const char*>(blob), static_cast<char*>(workspace), r.W, batch, frames, r.be};
+  c.cond_table(g);
+  c.enc_p(unit, noise, c.wsp<float>(r.W.z));
+  c.flow(c.wsp<float>(r.W.z));
+  c.dec_trunk(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post));
+  c.tail(c.wsp<float>(r.W.post), out, nullptr, frames * r.P.total_up + 1);
+  return c.status;
+}
+
+// Stage taps for debugging: copies frame-major fp32 buffers out of the workspace after a run.
+// which: 0 = z (after flow), 1 = post (conv_post output), 2 = stage-0 MRF mean, 3 = stage-1 MRF mean
+int64_t qvc_emu_tap_offset(const qvc_config* cfg, int32_t batch, int32_t frames, int32_t which) {
+  Plan P = build_plan(*cfg);
+  if (P.status != QVC_OK) return P.status;
+  Workspace W = carve_workspace(P, batch, frames);
+  switch (which) {
+    case 0: return W.z;
+    case 1: return W.post;
+    case 2: return W.m[0];
+    case 3: return W.m.size() > 1 ? W.m[1] : -1;
+    case 4: return W.u[0];
+    case 5: return W.stats;
+    default: return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""Builds the native code in-tree (no JIT cache: the built .so travels to the GPU box).
+
+  libqvc_hip.so      -- the product: gfx950 kernels + C ABI + host packer (hipcc --offload-arch=gfx950)
+  oracle/_build/libqvc_emu.so -- TEST-ONLY host emulation of the launch sequence (g++/hipcc host code)
+
+hipcc cross-compiles gfx950 without a GPU.  Translation units compile in parallel.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "csrc", "_obj")
+LIB = os.path.join(PKG, "libqvc_hip.so")
+EMU_DIR = os.path.join(ROOT, "oracle", "_build")
+EMU_LIB = os.path.join(EMU_DIR, "libqvc_emu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+SOURCES = ["qvc_conv_f16.hip", "qvc_conv_bf16.hip", "qvc_small.hip", "qvc_api.hip", "qvc_pack.cpp"]
+HEADERS = ["qvc_plan.h", "qvc_kernels.h", "qvc_conv_impl.h", "qvc_path.h", "qvc_pack_util.h"]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def _run(cmd):
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), res.stdout))
+    return res.stdout
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "qvc.h")]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or not _newer(o, [s] + hdrs):
+            jobs.append([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if jobs or not os.path.exists(LIB):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+def build_emu(force: bool = False) -> str:
+    """The oracle-side host emulation (tests only)."""
+    os.makedirs(EMU_DIR, exist_ok=True)
+    srcs = [os.path.join(ROOT, "oracle", "qvc_emu.cpp"), os.path.join(CSRC, "qvc_pack.cpp")]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "qvc.h")]
+    if force or not _newer(EMU_LIB, srcs + hdrs):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", EMU_LIB] + srcs)
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build_hip(force, verbose=True))
+    print(build_emu(force))

@@ -1,0 +1,178 @@
+// qvc_api.hip -- the C ABI of include/qvc.h: argument checks + the launch sequence of the path.
+//
+// Everything here is host code that only *enqueues* kernels on the caller's stream: no
+// allocation, no synchronisation, no host read of device data, so a whole qvc_infer_batch
+// call can be captured into a hipGraph by the caller.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "qvc_path.h"
+#include "qvc_pack_util.h"
+
+namespace qvc {
+int launch_fm_to_cm(const float* src, float* dst, int batch, int frames, int channels, void* stream);
+}
+
+namespace {
+using namespace qvc;
+
+struct HipBackend {
+  hipStream_t stream;
+  int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) { return launch_conv(d, a, batch, epi, dtype, stream); }
+  int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
+  int sample(const SampleArgs& a) { return launch_sample(a, stream); }
+  int tail(const TailArgs& a) { return launch_tail(a, stream); }
+  int zero(void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; }
+};
+using Ctx = Path<HipBackend>;
+
+int check_common(const qvc_config* cfg, const void* blob, int batch, int frames, void* ws, int64_t ws_bytes, Plan& P,
+                 Workspace& W) {
+  if (!cfg || !blob || !ws || batch <= 0 || frames <= 1) return QVC_ERR_BAD_ARG;
+  P = build_plan(*cfg);
+  if (P.status != QVC_OK) return P.status;
+  W = carve_workspace(P, batch, frames);
+  if (ws_bytes < W.bytes) return QVC_ERR_SMALL_BUFFER;
+  if ((reinterpret_cast<uintptr_t>(ws) & 255) || (reinterpret_cast<uintptr_t>(blob) & 255)) return QVC_ERR_BAD_ARG;
+  return QVC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qvc_abi_version(void) { return QVC_ABI_VERSION; }
+
+const char* qvc_status_string(int status) {
+  switch (status) {
+    case QVC_OK: return "ok";
+    case QVC_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size, misaligned buffer or bad enum)";
+    case QVC_ERR_BAD_CONFIG: return "unsupported model configuration";
+    case QVC_ERR_MISSING_TENSOR: return "a state-dict tensor needed by the path is missing";
+    case QVC_ERR_BAD_SHAPE: return "a state-dict tensor has an unexpected shape";
+    case QVC_ERR_SMALL_BUFFER: return "blob or workspace smaller than the matching *_bytes() query";
+    case QVC_ERR_LAUNCH: return "HIP kernel launch failed";
+    case QVC_ERR_NO_DEVICE: return "no gfx950 HIP device visible";
+    default: return "unknown status";
+  }
+}
+
+int qvc_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return QVC_ERR_NO_DEVICE;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return QVC_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return QVC_ERR_NO_DEVICE;
+  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? QVC_OK : QVC_ERR_NO_DEVICE;
+}
+
+int64_t qvc_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t frames) {
+  if (!cfg || batch <= 0 || frames <= 1) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  if (P.status != QVC_OK) return P.status;
+  return carve_workspace(P, batch, frames).bytes;
+}
+
+int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,
+                    const float* noise, float* out, int32_t batch, int32_t frames, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  if (!unit || !g || !noise || !out) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  HipBackend be{static_cast<hipStream_t>(stream)};
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.cond_table(g);
+  c.enc_p(unit, noise, c.wsp<float>(W.z));
+  c.flow(c.wsp<float>(W.z));
+  c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
+  c.tail(c.wsp<float>(W.post), out, nullptr, frames * P.total_up + 1);
+  return c.status;
+}
+
+int qvc_enc_p(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* noise, float* z_p_fm,
+              int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!unit || !noise || !z_p_fm) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  HipBackend be{static_cast<hipStream_t>(stream)};
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.enc_p(unit, noise, z_p_fm);
+  return c.status;
+}
+
+int qvc_flow_reverse(const qvc_config* cfg, const void* blob_dev, float* z_fm, const float* g, int32_t batch,
+                     int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!z_fm || !g) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  HipBackend be{static_cast<hipStream_t>(stream)};
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.cond_table(g);
+  c.flow(z_fm);
+  return c.status;
+}
+
+int qvc_dec_trunk(const qvc_config* cfg, const void* blob_dev, const float* z_fm, const float* g, float* post_fm,
+                  int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!z_fm || !g || !post_fm) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  HipBackend be{static_cast<hipStream_t>(stream)};
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.cond_table(g);
+  c.dec_trunk(z_fm, post_fm);
+  return c.status;
+}
+
+int qvc_istft_synth(const qvc_config* cfg, const void* blob_dev, const float* post_fm, float* out, float* y_mb,
+                    int32_t batch, int32_t post_frames, void* stream) {
+  if (!cfg || !blob_dev || !post_fm || !out || batch <= 0 || post_frames <= 1) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  if (P.status != QVC_OK) return P.status;
+  TailArgs ta{post_fm, reinterpret_cast<const float*>(static_cast<const char*>(blob_dev) + P.fir_off), out, y_mb, batch,
+              post_frames};
+  return launch_tail(ta, stream);
+}
+
+int64_t qvc_conv1d_scratch_bytes(int32_t cout, int32_t cin, int32_t k) {
+  if (cout <= 0 || cin <= 0 || k <= 0 || cout % 4 || cin % 8) return QVC_ERR_BAD_ARG;
+  ConvDesc d = make_conv(cout, cin, k, 1);
+  return align_up(d.w_bytes(), 256) + align_up(d.b_bytes(), 256);
+}
+
+int64_t qvc_conv1d_workspace_bytes(int32_t batch, int32_t cout, int32_t cin, int32_t frames) {
+  if (batch <= 0 || cout <= 0 || cin <= 0 || frames <= 0) return QVC_ERR_BAD_ARG;
+  return align_up((int64_t)batch * frames * cout * 4, 256);
+}
+
+int qvc_conv1d(const float* x, const float* w_host, const float* bias_host, float* y, int32_t batch, int32_t cin,
+               int32_t cout, int32_t frames, int32_t k, int32_t dilation, float slope_in, int32_t operand_dtype,
+               void* w_scratch_host, void* w_scratch_dev, int64_t scratch_bytes, void* workspace,
+               int64_t workspace_bytes, void* stream) {
+  if (!x || !w_host || !y || !w_scratch_host || !w_scratch_dev || !workspace) return QVC_ERR_BAD_ARG;
+  if (batch <= 0 || frames <= 0 || k <= 0 || k % 2 == 0 || dilation <= 0 || cout % 4 || cin % 8) return QVC_ERR_BAD_ARG;
+  if (operand_dtype != QVC_BF16 && operand_dtype != QVC_F16) return QVC_ERR_BAD_ARG;
+  ConvDesc d = make_conv(cout, cin, k, dilation);
+  d.w_off = 0; d.b_off = align_up(d.w_bytes(), 256);
+  if (scratch_bytes < d.b_off + align_up(d.b_bytes(), 256)) return QVC_ERR_SMALL_BUFFER;
+  if (workspace_bytes < qvc_conv1d_workspace_bytes(batch, cout, cin, frames)) return QVC_ERR_SMALL_BUFFER;
+  pack_plain_conv(d, w_host, bias_host, operand_dtype, static_cast<char*>(w_scratch_host));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(w_scratch_dev, w_scratch_host, (size_t)(d.b_off + d.b_bytes()), hipMemcpyHostToDevice, s) != hipSuccess)
+    return QVC_ERR_LAUNCH;
+  ConvArgs a;
+  a.w = w_scratch_dev;
+  a.bias = reinterpret_cast<const float*>(static_cast<const char*>(w_scratch_dev) + d.b_off);
+  a.x = x; a.x_kind = XK_F32_CM; a.x_bs = (int64_t)cin * frames; a.x_ts = frames; a.T_in = frames; a.slope_in = slope_in;
+  a.Nq = frames; a.T_out = frames;
+  a.y32 = static_cast<float*>(workspace); a.y32_bs = (int64_t)frames * cout; a.y32_ts = cout;
+  int st = launch_conv(d, a, batch, EPI_STD, operand_dtype, stream);
+  if (st != QVC_OK) return st;
+  return launch_fm_to_cm(static_cast<const float*>(workspace), y, batch, frames, cout, stream);
+}
+
+}  // extern "C"

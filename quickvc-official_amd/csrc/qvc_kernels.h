@@ -1,0 +1,71 @@
+// qvc_kernels.h -- launch-side view of the gfx950 kernels (arguments + launcher prototypes).
+#pragma once
+#include <cstdint>
+#include "qvc_plan.h"
+
+namespace qvc {
+
+enum XKind : int32_t {
+  XK_OP_FM = 0,    // operand type (f16/bf16), frame-major [B][T][C]
+  XK_F32_FM = 1,   // fp32, frame-major
+  XK_F32_CM = 2    // fp32, channel-major (B, C, T) -- the reference's external layout
+};
+
+// Arguments of one implicit-GEMM conv launch.  All strides in elements.
+struct ConvArgs {
+  // ---- input
+  const void* x = nullptr;
+  int32_t x_kind = XK_F32_FM;
+  int64_t x_bs = 0;        // batch stride
+  int32_t x_ts = 0;        // frame stride (frame-major) / channel stride (channel-major)
+  int32_t x_c0 = 0;        // first channel of the slice (frame-major)
+  int32_t Cin = 0, CinP = 0, T_in = 0;
+  float slope_in = 1.f;    // leaky-ReLU slope applied while staging (1 = identity)
+  int32_t reflect = 0;     // 1: ReflectionPad1d((1,0)) in front of a 'same' conv (models.py:345,388)
+  // ---- weights (A stream) and biases
+  const void* w = nullptr;
+  const float* bias = nullptr;     // [MP] or null
+  const float* bbias = nullptr;    // per-utterance bias (conditioning), natural channel order
+  int64_t bbias_bs = 0;
+  int32_t taps = 1, dil = 1, left = 0, KS = 1, nIt = 1, nchunk = 1, M = 0;
+  // ---- output mapping: column q, virtual row v -> frame o = q*up_s + v/Cout - up_p, channel v%Cout
+  int32_t Nq = 0, up_s = 1, up_p = 0, Cout = 0, T_out = 0;
+  // ---- epilogue
+  const float* res = nullptr; int64_t res_bs = 0; int32_t res_ts = 0, res_c0 = 0; float res_sign = 1.f;
+  float* y32 = nullptr; int64_t y32_bs = 0; int32_t y32_ts = 0, y32_c0 = 0; float y_scale = 1.f; int32_t y_accum = 0;
+  void* y16 = nullptr; int64_t y16_bs = 0; int32_t y16_ts = 0; float slope_out = 1.f;
+  // res/skip split (WN 1x1, modules.py:104-112): rows >= split go to y32b[.. v-split] += val
+  float* y32b = nullptr; int32_t split = 0;
+  int32_t gau_H = 0;       // EPI_GAU: hidden size (rows are [tanh | sigmoid])
+};
+
+struct GemvArgs {
+  const float* w; const float* bias; const float* g; float* out;
+  int32_t rows, gin, batch;
+};
+
+struct SampleArgs {   // z = mu + noise * exp(logs)   (models.py:93-94)
+  const float* stats; const float* noise; float* z;
+  int32_t batch, frames, C;
+};
+
+struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
+  const float* post;  // [B][F][subbands*18]
+  const float* fir;   // [subbands][63], gain folded
+  float* out;         // [B][subbands*hop*(F-1)]
+  float* y_mb;        // optional [B][subbands][hop*(F-1)]
+  int32_t batch, F;
+};
+
+struct DeviceInfo { int cus = 256; int lds_per_cu = 160 * 1024; };
+
+// Launchers return a QVC_* status.  `stream` is a hipStream_t.
+int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream);
+int launch_gemv(const GemvArgs& a, void* stream);
+int launch_sample(const SampleArgs& a, void* stream);
+int launch_tail(const TailArgs& a, void* stream);
+
+// Instantiation entry (one translation unit per operand dtype).
+template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream);
+
+}  // namespace qvc

@@ -1,0 +1,207 @@
+// qvc_path.h -- the launch sequence of the hot path, written once and parameterised on a backend.
+//
+// Backend = what "launch" means: the product's HipBackend (qvc_api.hip) enqueues gfx950 kernels
+// on a stream; the test-only host emulation under oracle/ replays the very same sequence on the
+// CPU from the same packed blob, which lets the orchestration (buffers, strides, flip folding,
+// fused epilogues) be checked against the oracle without a GPU.  The product never links the
+// emulation.
+//
+// A backend provides:  int conv(const ConvDesc&, const ConvArgs&, int batch, int epi, int dtype);
+//                      int gemv(const GemvArgs&); int sample(const SampleArgs&);
+//                      int tail(const TailArgs&); int zero(void* ptr, size_t bytes);
+#pragma once
+#include "qvc_kernels.h"
+
+namespace qvc {
+
+template <class Backend>
+struct Path {
+  const Plan& P;
+  const char* blob;
+  char* ws;
+  Workspace W;
+  int B, T;
+  Backend& be;
+  int status = QVC_OK;
+
+  template <typename U> U* wsp(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
+  int dtype() const { return P.cfg.operand_dtype; }
+
+  ConvArgs args(const ConvDesc& d) const {
+    ConvArgs a;
+    a.w = blob + d.w_off;
+    a.bias = d.b_off >= 0 ? reinterpret_cast<const float*>(blob + d.b_off) : nullptr;
+    a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left;
+    a.KS = d.KS(); a.nIt = d.nIt(); a.nchunk = d.nchunk; a.M = d.M;
+    a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout;
+    return a;
+  }
+  void conv(const ConvDesc& d, const ConvArgs& a, int epi = EPI_STD) {
+    if (status != QVC_OK) return;
+    status = be.conv(d, a, B, epi, dtype());
+  }
+  void zero(int64_t off, int64_t bytes) {
+    if (status != QVC_OK) return;
+    status = be.zero(ws + off, (size_t)bytes);
+  }
+
+  // ---- conditioning table: bb[b][row] for every cond row (flow WN layers + dec.cond)
+  void cond_table(const float* g) {
+    if (status != QVC_OK) return;
+    GemvArgs ga{reinterpret_cast<const float*>(blob + P.cond_w_off), reinterpret_cast<const float*>(blob + P.cond_b_off),
+                g, wsp<float>(W.bb), P.cond_rows, P.cfg.gin_channels, B};
+    status = be.gemv(ga);
+  }
+
+  // ---- WN stack over xw (in place) accumulating into oacc (modules.py:69-114)
+  // bb: conditioning rows for layer 0 (+ l*2H per layer), bb_bs: batch stride (0 = shared)
+  void wn(const WNPlan& wn, const float* bb, int64_t bb_bs) {
+    const int H = P.cfg.hidden_channels;
+    const int64_t bs = (int64_t)T * H;
+    zero(W.oacc, (int64_t)B * bs * 4);
+    for (int l = 0; l < wn.layers; ++l) {
+      {   // k-tap conv h->2h + conditioning + tanh*sigmoid gate  (modules.py:91-101)
+        ConvArgs a = args(wn.in_conv[l]);
+        a.x = wsp<float>(W.xw); a.x_kind = XK_F32_FM; a.x_bs = bs; a.x_ts = H; a.T_in = T;
+        a.Nq = T; a.T_out = T;
+        a.bbias = bb + (int64_t)l * 2 * H; a.bbias_bs = bb_bs; a.gau_H = H;
+        a.y16 = wsp<void>(W.acts); a.y16_bs = bs; a.y16_ts = H;
+        conv(wn.in_conv[l], a, EPI_GAU);
+      }
+      {   // 1x1 h->2h: x += first half, out += second half (everything on the last layer)  (:104-112)
+        ConvArgs a = args(wn.rs_conv[l]);
+        a.x = wsp<void>(W.acts); a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = H; a.T_in = T;
+        a.Nq = T; a.T_out = T;
+        a.y32b = wsp<float>(W.oacc); a.y32_bs = bs; a.y32_ts = H;
+        if (l < wn.layers - 1) {
+          a.split = H;
+          a.res = wsp<float>(W.xw); a.res_bs = bs; a.res_ts = H;
+          a.y32 = wsp<float>(W.xw);
+        } else {
+          a.split = 0;
+        }
+        conv(wn.rs_conv[l], a);
+      }
+    }
+  }
+
+  // ---- enc_p (models.py:75-95)
+  void enc_p(const float* unit, const float* noise, float* z_out) {
+    const qvc_config& c = P.cfg;
+    const int H = c.hidden_channels, C = c.inter_channels;
+    {
+      ConvArgs a = args(P.enc_pre);
+      a.x = unit; a.x_kind = XK_F32_CM; a.x_bs = (int64_t)c.unit_channels * T; a.x_ts = T; a.T_in = T;
+      a.Nq = T; a.T_out = T;
+      a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
+      conv(P.enc_pre, a);
+    }
+    wn(P.enc_wn, reinterpret_cast<const float*>(blob + P.enc_wn.inbias_off), 0);
+    {
+      ConvArgs a = args(P.enc_proj);
+      a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
+      a.Nq = T; a.T_out = T;
+      a.y32 = wsp<float>(W.stats); a.y32_bs = (int64_t)T * 2 * C; a.y32_ts = 2 * C;
+      conv(P.enc_proj, a);
+    }
+    if (status != QVC_OK) return;
+    SampleArgs sa{wsp<float>(W.stats), noise, z_out, B, T, C};
+    status = be.sample(sa);
+  }
+
+  // ---- flow, reverse (models.py:39-51, modules.py:199-224); z updated in place
+  void flow(float* z) {
+    const qvc_config& c = P.cfg;
+    const int H = c.hidden_channels, C = c.inter_channels;
+    const float* bb = wsp<float>(W.bb);
+    for (const FlowStepPlan& f : P.flow) {
+      {
+        ConvArgs a = args(f.pre);
+        a.x = z; a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * C; a.x_ts = C; a.x_c0 = f.in_c0; a.T_in = T;
+        a.Nq = T; a.T_out = T;
+        a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
+        conv(f.pre, a);
+      }
+      wn(f.wn, bb + f.cond_row0, P.cond_rows);
+      {   // x1 <- x1 - post(h)   (modules.py:214-217)
+        ConvArgs a = args(f.post);
+        a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
+        a.Nq = T; a.T_out = T;
+        a.res = z; a.res_bs = (int64_t)T * C; a.res_ts = C; a.res_c0 = f.out_c0; a.res_sign = -1.f;
+        a.y32 = z; a.y32_bs = (int64_t)T * C; a.y32_ts = C; a.y32_c0 = f.out_c0;
+        conv(f.post, a);
+      }
+    }
+  }
+
+  // ---- generator trunk (models.py:372-390)
+  void dec_trunk(const float* z, float* post_out) {
+    const qvc_config& c = P.cfg;
+    const int C = c.inter_channels, C0 = c.upsample_initial_channel;
+    {   // conv_pre(k7) + cond(g), then the first stage's leaky ReLU fused into the store
+      ConvArgs a = args(P.conv_pre);
+      a.x = z; a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * C; a.x_ts = C; a.T_in = T;
+      a.Nq = T; a.T_out = T;
+      a.bbias = wsp<float>(W.bb) + P.dec_cond_row0; a.bbias_bs = P.cond_rows;
+      a.y16 = wsp<void>(W.c0); a.y16_bs = (int64_t)T * C0; a.y16_ts = C0; a.slope_out = 0.1f;
+      conv(P.conv_pre, a);
+    }
+    int t_in = T, ch_in = C0;
+    for (size_t i = 0; i < P.stages.size(); ++i) {
+      const StagePlan& st = P.stages[i];
+      const int s = st.up.up_s, p = st.up.up_p, k = c.upsample_kernel_sizes[i];
+      const int t_out = (t_in - 1) * s - 2 * p + k + (1 - (int)i);         // models.py:335
+      const int ch = st.ch;
+      const int64_t bs = (int64_t)t_out * ch;
+      {   // lrelu(0.1) -> ConvTranspose1d as `s` polyphase filters
+        ConvArgs a = args(st.up);
+        if (i == 0) { a.x = wsp<void>(W.c0); a.x_kind = XK_OP_FM; }
+        else { a.x = wsp<float>(W.m[i - 1]); a.x_kind = XK_F32_FM; a.slope_in = 0.1f; }
+        a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in; a.T_in = t_in;
+        a.Nq = (t_out - 1 + p) / s + 1; a.T_out = t_out;
+        a.y32 = wsp<float>(W.u[i]); a.y32_bs = bs; a.y32_ts = ch;
+        conv(st.up, a);
+      }
+      for (int j = 0; j < c.n_resblocks; ++j) {
+        const float* src = wsp<float>(W.u[i]);
+        for (int q = 0; q < 3; ++q) {
+          {   // lrelu -> dilated conv -> lrelu (stored already activated, operand type)
+            ConvArgs a = args(st.c1[(size_t)j * 3 + q]);
+            a.x = src; a.x_kind = XK_F32_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out; a.slope_in = 0.1f;
+            a.Nq = t_out; a.T_out = t_out;
+            a.y16 = wsp<void>(W.xt[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 0.1f;
+            conv(st.c1[(size_t)j * 3 + q], a);
+          }
+          {   // conv -> + x ; the last pair of each ResBlock goes straight into the MRF mean
+            ConvArgs a = args(st.c2[(size_t)j * 3 + q]);
+            a.x = wsp<void>(W.xt[i]); a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
+            a.Nq = t_out; a.T_out = t_out;
+            a.res = src; a.res_bs = bs; a.res_ts = ch;
+            a.y32_bs = bs; a.y32_ts = ch;
+            if (q < 2) { a.y32 = wsp<float>(W.r[i]); }
+            else { a.y32 = wsp<float>(W.m[i]); a.y_scale = 1.f / (float)c.n_resblocks; a.y_accum = j > 0 ? 1 : 0; }
+            conv(st.c2[(size_t)j * 3 + q], a);
+          }
+          src = wsp<float>(W.r[i]);
+        }
+      }
+      t_in = t_out; ch_in = ch;
+    }
+    {   // lrelu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post(k7)
+      ConvArgs a = args(P.conv_post);
+      a.x = wsp<float>(W.m[P.stages.size() - 1]); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in;
+      a.T_in = t_in; a.slope_in = 0.01f; a.reflect = 1;
+      a.Nq = t_in + 1; a.T_out = t_in + 1;
+      a.y32 = post_out; a.y32_bs = (int64_t)(t_in + 1) * P.post_channels; a.y32_ts = P.post_channels;
+      conv(P.conv_post, a);
+    }
+  }
+
+  void tail(const float* post, float* out, float* y_mb, int F) {
+    if (status != QVC_OK) return;
+    TailArgs ta{post, reinterpret_cast<const float*>(blob + P.fir_off), out, y_mb, B, F};
+    status = be.tail(ta);
+  }
+};
+
+}  // namespace qvc

@@ -1,0 +1,271 @@
+// qvc_plan.h -- weight-blob layout ("plan") shared by the host packer, the device
+// orchestration and the test-only host emulation.  Header-only, plain C++17, no HIP.
+//
+// The plan is a pure function of qvc_config: every conv of the hot path gets a
+// descriptor (shapes, padded shapes, byte offsets into the blob).  Nothing here is
+// stored in the blob itself, so packer and runtime can never disagree.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../include/qvc.h"
+
+namespace qvc {
+
+constexpr int kWaves = 4;          // waves per workgroup in the conv kernel (M split)
+constexpr int kKStep = 32;         // MFMA 16x16x32: K elements per step
+constexpr int kFragElems = 512;    // one A fragment = 64 lanes x 8 elements
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+enum EpiKind : int32_t { EPI_STD = 0, EPI_GAU = 1, EPI_RESSKIP = 2 };
+
+// One conv expressed as an implicit GEMM  D[v][q] = sum_{tap,ci} Wv[v][tap][ci] * X[q + tap*dil - left][ci].
+struct ConvDesc {
+  int32_t M = 0;        // virtual output channels (s*Cout for a polyphase transposed conv)
+  int32_t MF = 1;       // A fragments (16 rows) per wave
+  int32_t nchunk = 1;   // M chunks of kWaves*MF*16 rows
+  int32_t Cin = 0;      // real input channels
+  int32_t CinP = 0;     // padded to a multiple of 32
+  int32_t taps = 1, dil = 1, left = 0;
+  int32_t up_s = 1, up_p = 0;   // polyphase: stride / padding of the ConvTranspose1d (1/0: plain conv)
+  int32_t Cout = 0;     // real output channels (M = up_s * Cout)
+  int32_t gau = 0;      // 1: rows permuted so that a wave owns tanh and sigmoid rows of the same channels
+  int64_t w_off = 0;    // byte offset of the A stream
+  int64_t b_off = 0;    // byte offset of the fp32 bias [MP]
+  int32_t MP() const { return nchunk * kWaves * MF * 16; }
+  int32_t KS() const { return CinP / kKStep; }
+  int32_t nIt() const { return taps * KS(); }
+  int64_t w_bytes() const { return (int64_t)nchunk * kWaves * nIt() * MF * kFragElems * 2; }
+  int64_t b_bytes() const { return (int64_t)MP() * 4; }
+};
+
+// Row permutation of the A stream: packed position -> original output channel (or -1 = zero padding).
+inline int conv_row(const ConvDesc& d, int chunk, int wave, int mf, int i) {
+  if (!d.gau) {
+    int v = ((chunk * kWaves + wave) * d.MF + mf) * 16 + i;
+    return v < d.M ? v : -1;
+  }
+  // GAU: MF == 2, mf 0 = tanh half, mf 1 = sigmoid half, 64 channels per chunk
+  int H = d.M / 2;
+  int ch = chunk * 64 + wave * 16 + i;
+  return ch < H ? mf * H + ch : -1;
+}
+
+inline void choose_mf(ConvDesc& d) {
+  if (d.gau) { d.MF = 2; d.nchunk = ceil_div(d.M / 2, 64); return; }
+  int best_mf = 1, best_cost = 1 << 30;
+  for (int mf = 1; mf <= 4; ++mf) {
+    int nch = ceil_div(d.M, kWaves * mf * 16);
+    int cost = nch * mf;
+    if (cost < best_cost || (cost == best_cost && mf > best_mf)) { best_cost = cost; best_mf = mf; }
+  }
+  d.MF = best_mf;
+  d.nchunk = ceil_div(d.M, kWaves * best_mf * 16);
+}
+
+struct WNPlan {
+  int32_t layers = 0;
+  std::vector<ConvDesc> in_conv;   // k-tap h -> 2h, GAU row order; bias lives in the cond/bias table
+  std::vector<ConvDesc> rs_conv;   // 1x1 h -> 2h (h on the last layer)
+  int64_t inbias_off = -1;         // enc_p only: fp32 [layers][2h] in_layer biases (no conditioning)
+};
+
+struct FlowStepPlan {
+  int32_t layer = 0;       // index into flow.flows (0,2,4,6 -> 0..3)
+  int32_t flipped = 0;     // 1: logical channel c lives at physical channel C-1-c
+  int32_t in_c0 = 0;       // physical first channel read by pre
+  int32_t out_c0 = 0;      // physical first channel updated by post
+  ConvDesc pre, post;
+  WNPlan wn;
+  int32_t cond_row0 = 0;   // first row of this step's block in the cond table ([layers][2h])
+};
+
+struct StagePlan {
+  ConvDesc up;
+  std::vector<ConvDesc> c1, c2;   // [resblock j][pair p] flattened: j*3+p
+  int32_t ch = 0;                 // channels of this stage
+  int32_t rate = 1;
+};
+
+struct Plan {
+  qvc_config cfg{};
+  int32_t status = QVC_OK;
+  ConvDesc enc_pre, enc_proj;
+  WNPlan enc_wn;
+  std::vector<FlowStepPlan> flow;   // in execution order (reverse=True)
+  ConvDesc conv_pre;
+  int32_t dec_cond_row0 = 0;        // rows [dec_cond_row0, +init_ch) of the cond table
+  std::vector<StagePlan> stages;
+  ConvDesc conv_post;
+  int32_t post_channels = 0;        // subbands * 2 * (n_fft/2+1)
+  int32_t total_up = 1;             // prod(upsample_rates)
+  // cond GEMV: fp32 weights [cond_rows][gin] + bias [cond_rows]
+  int32_t cond_rows = 0;
+  int64_t cond_w_off = 0, cond_b_off = 0;
+  // synthesis FIR: fp32 [subbands][fir_taps], zero-stuffing gain folded in
+  int64_t fir_off = 0;
+  int64_t blob_bytes = 0;
+};
+
+inline int validate(const qvc_config& c) {
+  auto bad = [](bool cond) { return cond; };
+  if (bad(c.unit_channels <= 0 || c.inter_channels <= 0 || c.hidden_channels <= 0 || c.gin_channels <= 0)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.inter_channels % 8 || c.hidden_channels % 8 || c.unit_channels % 8)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.wn_kernel_size < 1 || c.wn_kernel_size % 2 == 0 || c.wn_kernel_size > 15)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.enc_layers < 1 || c.enc_layers > 64 || c.flow_layers < 1 || c.flow_layers > 64)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.n_flows < 1 || c.n_flows > 16 || c.n_flows % 2)) return QVC_ERR_BAD_CONFIG;   // flips must cancel
+  if (bad(c.n_ups < 1 || c.n_ups > QVC_MAX_UPS || c.n_resblocks < 1 || c.n_resblocks > QVC_MAX_RESBLOCKS)) return QVC_ERR_BAD_CONFIG;
+  int ch = c.upsample_initial_channel;
+  if (bad(ch <= 0 || ch % 8)) return QVC_ERR_BAD_CONFIG;
+  for (int i = 0; i < c.n_ups; ++i) {
+    int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+    if (bad(s < 1 || s > 16 || k < s || k > 64)) return QVC_ERR_BAD_CONFIG;
+    if (bad(ch % 2)) return QVC_ERR_BAD_CONFIG;
+    ch /= 2;
+    if (bad(ch % 8)) return QVC_ERR_BAD_CONFIG;
+  }
+  for (int j = 0; j < c.n_resblocks; ++j) {
+    int k = c.resblock_kernel_sizes[j];
+    if (bad(k < 1 || k % 2 == 0 || k > 15)) return QVC_ERR_BAD_CONFIG;
+    for (int p = 0; p < 3; ++p) if (bad(c.resblock_dilations[j][p] < 1 || c.resblock_dilations[j][p] > 16)) return QVC_ERR_BAD_CONFIG;
+  }
+  if (bad(c.n_fft != 16 || c.hop != 4)) return QVC_ERR_BAD_CONFIG;           // the tail kernel is built for 16/4
+  if (bad(c.decoder != QVC_DEC_MULTISTREAM && c.decoder != QVC_DEC_MULTIBAND)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.subbands != 4 || c.fir_taps != 63)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.operand_dtype != QVC_BF16 && c.operand_dtype != QVC_F16)) return QVC_ERR_BAD_CONFIG;
+  return QVC_OK;
+}
+
+inline ConvDesc make_conv(int M, int Cin, int taps, int dil, bool gau = false) {
+  ConvDesc d;
+  d.M = M; d.Cout = M; d.Cin = Cin; d.CinP = (int)align_up(Cin, kKStep);
+  d.taps = taps; d.dil = dil; d.left = (taps - 1) / 2 * dil; d.gau = gau ? 1 : 0;
+  choose_mf(d);
+  return d;
+}
+
+inline ConvDesc make_upconv(int Cin, int Cout, int k, int s, int p) {
+  ConvDesc d;
+  d.up_s = s; d.up_p = p; d.Cout = Cout; d.M = s * Cout;
+  d.Cin = Cin; d.CinP = (int)align_up(Cin, kKStep);
+  d.taps = ceil_div(k, s); d.dil = 1; d.left = d.taps - 1;
+  choose_mf(d);
+  return d;
+}
+
+inline Plan build_plan(const qvc_config& c) {
+  Plan P;
+  P.cfg = c;
+  P.status = validate(c);
+  if (P.status != QVC_OK) return P;
+  int64_t off = 0;
+  auto place = [&](ConvDesc& d, bool with_bias = true) {
+    d.w_off = off; off = align_up(off + d.w_bytes(), 256);
+    if (with_bias) { d.b_off = off; off = align_up(off + d.b_bytes(), 256); } else { d.b_off = -1; }
+  };
+  const int H = c.hidden_channels, C = c.inter_channels, K = c.wn_kernel_size;
+  auto make_wn = [&](WNPlan& w, int layers) {
+    w.layers = layers;
+    for (int i = 0; i < layers; ++i) {
+      ConvDesc a = make_conv(2 * H, H, K, 1, /*gau=*/true);
+      place(a, /*with_bias=*/false);
+      w.in_conv.push_back(a);
+      ConvDesc r = make_conv(i < layers - 1 ? 2 * H : H, H, 1, 1);
+      place(r);
+      w.rs_conv.push_back(r);
+    }
+  };
+  // ---- enc_p
+  P.enc_pre = make_conv(H, c.unit_channels, 1, 1); place(P.enc_pre);
+  make_wn(P.enc_wn, c.enc_layers);
+  P.enc_wn.inbias_off = off; off = align_up(off + (int64_t)c.enc_layers * 2 * H * 4, 256);
+  P.enc_proj = make_conv(2 * C, H, 1, 1); place(P.enc_proj);
+  // ---- flow, execution order of reverse=True: Flip, L(n-1), Flip, L(n-2), ...
+  int cond_rows = 0;
+  bool flipped = false;
+  for (int s = 0; s < c.n_flows; ++s) {
+    FlowStepPlan f;
+    flipped = !flipped;                       // the Flip that precedes the layer
+    f.layer = c.n_flows - 1 - s;
+    f.flipped = flipped ? 1 : 0;
+    f.in_c0 = flipped ? C / 2 : 0;
+    f.out_c0 = flipped ? 0 : C / 2;
+    f.pre = make_conv(H, C / 2, 1, 1); place(f.pre);
+    make_wn(f.wn, c.flow_layers);
+    f.post = make_conv(C / 2, H, 1, 1); place(f.post);
+    f.cond_row0 = cond_rows; cond_rows += c.flow_layers * 2 * H;
+    P.flow.push_back(f);
+  }
+  // ---- decoder
+  P.conv_pre = make_conv(c.upsample_initial_channel, C, 7, 1); place(P.conv_pre);
+  P.dec_cond_row0 = cond_rows; cond_rows += c.upsample_initial_channel;
+  int ch = c.upsample_initial_channel;
+  for (int i = 0; i < c.n_ups; ++i) {
+    StagePlan st;
+    int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+    int p = (k - s + 1 - i) / 2;              // models.py:335 (output_padding 1-i only sets T_out)
+    st.up = make_upconv(ch, ch / 2, k, s, p); place(st.up);
+    ch /= 2; st.ch = ch; st.rate = s; P.total_up *= s;
+    for (int j = 0; j < c.n_resblocks; ++j)
+      for (int q = 0; q < 3; ++q) {
+        ConvDesc a = make_conv(ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilations[j][q]); place(a);
+        ConvDesc b = make_conv(ch, ch, c.resblock_kernel_sizes[j], 1); place(b);
+        st.c1.push_back(a); st.c2.push_back(b);
+      }
+    P.stages.push_back(st);
+  }
+  P.post_channels = c.subbands * 2 * (c.n_fft / 2 + 1);
+  P.conv_post = make_conv(P.post_channels, ch, 7, 1); place(P.conv_post);
+  // ---- cond GEMV table and FIR
+  P.cond_rows = cond_rows;
+  P.cond_w_off = off; off = align_up(off + (int64_t)cond_rows * c.gin_channels * 4, 256);
+  P.cond_b_off = off; off = align_up(off + (int64_t)cond_rows * 4, 256);
+  P.fir_off = off; off = align_up(off + (int64_t)c.subbands * c.fir_taps * 4, 256);
+  P.blob_bytes = off;
+  return P;
+}
+
+// ---------------------------------------------------------------- workspace carve-up
+struct Workspace {
+  int64_t bb = 0;        // fp32 [B][cond_rows]         cond GEMV output (+ folded biases)
+  int64_t xw = 0;        // fp32 [B][T][H]              WN residual stream
+  int64_t oacc = 0;      // fp32 [B][T][H]              WN skip accumulator
+  int64_t acts = 0;      // op   [B][T][H]              gated activations
+  int64_t stats = 0;     // fp32 [B][T][2C]             enc_p.proj output
+  int64_t z = 0;         // fp32 [B][T][C]              latent (flow state)
+  int64_t c0 = 0;        // op   [B][T][init_ch]        lrelu(conv_pre + cond)
+  std::vector<int64_t> u, r, m, xt;   // per stage: up output, resblock stream, MRF mean (fp32), conv1 output (op)
+  int64_t post = 0;      // fp32 [B][F][post_channels]
+  int64_t bytes = 0;
+};
+
+inline Workspace carve_workspace(const Plan& P, int B, int T) {
+  Workspace W;
+  const qvc_config& c = P.cfg;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off = align_up(off + n, 256); return o; };
+  const int64_t BT = (int64_t)B * T;
+  W.bb = take((int64_t)B * P.cond_rows * 4);
+  W.xw = take(BT * c.hidden_channels * 4);
+  W.oacc = take(BT * c.hidden_channels * 4);
+  W.acts = take(BT * c.hidden_channels * 2);
+  W.stats = take(BT * 2 * c.inter_channels * 4);
+  W.z = take(BT * c.inter_channels * 4);
+  W.c0 = take(BT * c.upsample_initial_channel * 2);
+  int64_t t = T;
+  for (size_t i = 0; i < P.stages.size(); ++i) {
+    t *= P.stages[i].rate;
+    int64_t n = (int64_t)B * t * P.stages[i].ch;
+    W.u.push_back(take(n * 4));
+    W.r.push_back(take(n * 4));
+    W.m.push_back(take(n * 4));
+    W.xt.push_back(take(n * 2));
+  }
+  W.post = take((int64_t)B * (t + 1) * P.post_channels * 4);
+  W.bytes = off;
+  return W;
+}
+
+}  // namespace qvc

@@ -1,0 +1,230 @@
+// qvc_small.hip -- the HBM-bound kernels around the conv trunk:
+//   * cond_gemv_kernel   : all 1x1 conditioning convs on g (modules.py:54,84; models.py:328,372)
+//   * sample_kernel      : z_p = mu + noise*exp(logs) (models.py:93-94), noise read in (B,C,T)
+//   * istft_synth_kernel : exp / pi*sin / 16-point inverse real DFT / Hann overlap-add /
+//                          envelope / x4 zero-stuff / 63-tap synthesis FIR in ONE pass
+//                          (models.py:394-406, pqmf.py:106-117) -- no complex tensors, no
+//                          zero-stuffed intermediate, each post-conv frame read once (+halo).
+//   * fm_to_cm_kernel    : frame-major -> (B,C,T) for the unit-test conv entry point.
+#include <hip/hip_runtime.h>
+#include "qvc_kernels.h"
+
+namespace qvc {
+
+// ------------------------------------------------------------------ cond GEMV
+// out[b][row] = bias[row] + sum_k w[row][k] * g[b][k].  One wave per row; the row (<= a few KB)
+// is read once, coalesced, and reused for every utterance of the batch.
+__global__ __launch_bounds__(256) void cond_gemv_kernel(const GemvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const float* wr = a.w + (size_t)row * a.gin;
+  const float bias = a.bias[row];
+  for (int b = 0; b < a.batch; ++b) {
+    const float* gb = a.g + (size_t)b * a.gin;
+    float s = 0.f;
+    for (int k = lane; k < a.gin; k += 64) s = fmaf(wr[k], gb[k], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) a.out[(size_t)b * a.rows + row] = s + bias;
+  }
+}
+
+int launch_gemv(const GemvArgs& a, void* stream) {
+  if (a.rows <= 0) return QVC_OK;
+  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ sampling
+__global__ __launch_bounds__(256) void sample_kernel(const SampleArgs a) {
+  const size_t n = (size_t)a.batch * a.frames * a.C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % a.C);
+    const size_t bt = i / a.C;
+    const int t = (int)(bt % a.frames);
+    const size_t b = bt / a.frames;
+    const float mu = a.stats[bt * 2 * a.C + c], logs = a.stats[bt * 2 * a.C + a.C + c];
+    const float eps = a.noise[(b * a.C + c) * a.frames + t];
+    a.z[i] = mu + eps * expf(logs);
+  }
+}
+
+int launch_sample(const SampleArgs& a, void* stream) {
+  const size_t n = (size_t)a.batch * a.frames * a.C;
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ iSTFT + band synthesis tail
+// Geometry (n_fft 16, hop 4, 4 sub-bands, 63 taps):
+//   band signal   y_k[n], n in [0, 4(F-1)):  y = (sum_t w[m] x_t[m]) / (sum_t w[m]^2), m = n + 8 - 4t
+//   output        out[o], o in [0, 16(F-1)): out[o] = sum_k sum_n fir[k][4n - o + 31] * y_k[n]
+// One block = kOT consecutive output samples = kOT/4 band samples (+-7/8 halo) = kOT/16 frames (+-3/4).
+constexpr int kOT = 1024;                  // output samples per block
+constexpr int kNY = kOT / 4 + 15;          // band samples needed: [a0-7, a0+kOT/4+7]
+constexpr int kNFR = kOT / 16 + 7;         // frames needed: [f0-3, f0+kOT/16+3]
+constexpr int kBands = 4, kBins = 9, kPostC = kBands * 2 * kBins, kTaps = 63;
+
+__global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_post[kNFR * kPostC];    // 20.4 KB
+  __shared__ float s_xw[kBands][kNFR][17];                                // windowed frames (padded)
+  __shared__ float s_y[kBands][kNY + 1];
+  __shared__ float s_fir[kBands * 64];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int o0 = blockIdx.x * kOT;
+  const int a0 = o0 >> 2;                   // first band sample owned by this block
+  const int f_lo = (o0 >> 4) - 3;           // first frame staged
+  const int L = 4 * (a.F - 1);              // band signal length
+  const float* pb = a.post + (size_t)b * a.F * kPostC;
+
+  // ---- stage frames [f_lo, f_lo+kNFR) x 72 channels (contiguous in memory), float4 coalesced
+  for (int i = tid; i < kNFR * (kPostC / 4); i += 256) {
+    const int fr = i / (kPostC / 4), c4 = i - fr * (kPostC / 4);
+    const int t = f_lo + fr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < a.F) v = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
+    *reinterpret_cast<float4*>(&s_post[fr * kPostC + c4 * 4]) = v;
+  }
+  if (tid < kBands * 64) {
+    const int k = tid >> 6, j = tid & 63;
+    s_fir[tid] = j < kTaps ? a.fir[k * kTaps + j] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- per (frame, band): polar -> 16-point inverse real DFT -> Hann window
+  constexpr float kPi = 3.14159265358979323846f;
+  for (int item = tid; item < kNFR * kBands; item += 256) {
+    const int fr = item >> 2, k = item & 3;
+    const float* sp = &s_post[fr * kPostC + k * 2 * kBins];
+    float re[kBins], im[kBins];
+#pragma unroll
+    for (int q = 0; q < kBins; ++q) {
+      const float mag = expf(sp[q]);
+      const float ph = kPi * sinf(sp[kBins + q]);
+      float sn, cs;
+      sincosf(ph, &sn, &cs);
+      re[q] = mag * cs; im[q] = mag * sn;
+    }
+    // twiddles cos/sin(2*pi*j/16), j = 0..15, as compile-time constants after unrolling
+    constexpr float C16[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
+                               -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
+                               -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.f,
+                               0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+    constexpr float S16[16] = {0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.f,
+                               0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
+                               -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
+                               -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      float acc = re[0] + ((m & 1) ? -re[8] : re[8]);      // imaginary parts of bins 0 and 8 are ignored
+#pragma unroll
+      for (int q = 1; q < 8; ++q) {
+        const int j = (q * m) & 15;
+        acc += 2.f * (re[q] * C16[j] - im[q] * S16[j]);
+      }
+      const float win = 0.5f - 0.5f * C16[m];               // periodic Hann(16)
+      s_xw[k][fr][m] = acc * (1.f / 16.f) * win;
+    }
+  }
+  __syncthreads();
+
+  // ---- overlap-add + envelope: band samples n = a0 - 7 + i
+  for (int item = tid; item < kNY * kBands; item += 256) {
+    const int k = item / kNY, i = item - k * kNY;
+    const int n = a0 - 7 + i;
+    float y = 0.f;
+    if (n >= 0 && n < L) {
+      constexpr float C16b[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
+                                  -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
+                                  -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.f,
+                                  0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+      float num = 0.f, env = 0.f;
+      const int t_hi = (n + 8) >> 2;                         // frames with m = n + 8 - 4t in [0, 16)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int t = t_hi - d, m = n + 8 - 4 * t;
+        if (t >= 0 && t < a.F && m < 16) {
+          const float w = 0.5f - 0.5f * C16b[m];
+          num += s_xw[k][t - f_lo][m];
+          env += w * w;
+        }
+      }
+      y = num / env;
+    }
+    s_y[k][i] = y;
+    if (a.y_mb && i >= 7 && i < 7 + kOT / 4 && n < L)
+      a.y_mb[((size_t)b * kBands + k) * L + n] = y;
+  }
+  __syncthreads();
+
+  // ---- polyphase synthesis FIR: thread -> 4 consecutive outputs o = o0 + 4*tid + r
+  {
+    const int ia = tid + 7;                                  // s_y index of band sample a = a0 + tid
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kBands; ++k) {
+#pragma unroll
+      for (int d = -7; d <= 8; ++d) {
+        const float yv = s_y[k][ia + d];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 4 * d - r + 31;                      // tap index, compile-time after unrolling
+          if (j >= 0 && j < kTaps) out[r] = fmaf(s_fir[k * 64 + j], yv, out[r]);
+        }
+      }
+    }
+    const int o = o0 + 4 * tid;
+    const int n_out = 4 * L;
+    if (o + 3 < n_out) {
+      *reinterpret_cast<float4*>(a.out + (size_t)b * n_out + o) = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+      for (int r = 0; r < 4; ++r) if (o + r < n_out) a.out[(size_t)b * n_out + o + r] = out[r];
+    }
+  }
+}
+
+int launch_tail(const TailArgs& a, void* stream) {
+  const int n_out = 16 * (a.F - 1);
+  if (n_out <= 0) return QVC_ERR_BAD_ARG;
+  hipLaunchKernelGGL(istft_synth_kernel, dim3((unsigned)ceil_div(n_out, kOT), (unsigned)a.batch), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ frame-major -> channel-major
+__global__ __launch_bounds__(256) void fm_to_cm_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int batch, int frames, int channels) {
+  const size_t n = (size_t)batch * frames * channels;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % frames);
+    const size_t bc = i / frames;
+    const int c = (int)(bc % channels);
+    const size_t b = bc / channels;
+    dst[i] = src[(b * frames + t) * channels + c];
+  }
+}
+
+int launch_fm_to_cm(const float* src, float* dst, int batch, int frames, int channels, void* stream) {
+  const size_t n = (size_t)batch * frames * channels;
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(fm_to_cm_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, batch,
+                     frames, channels);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ conv dispatcher
+int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream) {
+  a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left;
+  a.KS = d.KS(); a.nIt = d.nIt(); a.nchunk = d.nchunk; a.M = d.M;
+  a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout;
+  if (dtype == QVC_F16) return launch_conv_typed<_Float16>(d, a, batch, epi, stream);
+  if (dtype == QVC_BF16) return launch_conv_typed<__bf16>(d, a, batch, epi, stream);
+  return QVC_ERR_BAD_ARG;
+}
+
+}  // namespace qvc

@@ -1,0 +1,126 @@
+"""QvcEngine: owns the packed weights and workspace on one GPU and calls the C ABI.
+
+PyTorch is used here for device memory and streams only; every FLOP of enc_p / flow / dec
+runs inside libqvc_hip.so.  Buffers are PyTorch allocations handed over as raw pointers;
+kernels are enqueued on ``torch.cuda.current_stream()`` so the call composes with PyTorch
+work (the LSTM speaker encoder) and can be captured in a ``torch.cuda.CUDAGraph``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+
+
+def _aligned_empty(nbytes: int, device) -> torch.Tensor:
+    raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    shift = (-raw.data_ptr()) % 256
+    return raw[shift:shift + nbytes]
+
+
+class QvcEngine:
+    def __init__(self, model_config: dict, state_dict: Dict[str, torch.Tensor], device):
+        self.lib = L.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.QvcError("QvcEngine needs a HIP device (no CPU fallback)")
+        with torch.cuda.device(self.device):
+            L.check(self.lib, self.lib.qvc_device_check(), "qvc_device_check")
+        self.model_config = dict(model_config)
+        self.cfg = L.make_config(model_config)
+        host_blob = L.pack_weights(self.lib, self.cfg, state_dict)
+        self.blob = _aligned_empty(host_blob.numel(), self.device)
+        self.blob.copy_(host_blob)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key = None
+        n = model_config["gen_istft_hop_size"] * model_config["subbands"]
+        for u in model_config["upsample_rates"]:
+            n *= u
+        self.samples_per_frame = n
+
+    # weights can also arrive from another rank (one broadcast at start-up)
+    def load_blob_(self, blob: torch.Tensor) -> None:
+        self.blob.copy_(blob)
+
+    def workspace(self, batch: int, frames: int) -> torch.Tensor:
+        key = (batch, frames)
+        if self._ws is None or self._ws_key != key:
+            n = int(self.lib.qvc_workspace_bytes(ctypes.byref(self.cfg), batch, frames))
+            if n < 0:
+                L.check(self.lib, n, "qvc_workspace_bytes")
+            if self._ws is None or self._ws.numel() < n:
+                self._ws = _aligned_empty(n, self.device)
+            self._ws_key = key
+        return self._ws
+
+    @staticmethod
+    def _f32(t: torch.Tensor, device) -> torch.Tensor:
+        return t.to(device=device, dtype=torch.float32).contiguous()
+
+    def infer_batch(self, unit: torch.Tensor, g: torch.Tensor, noise: torch.Tensor,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """unit (B,256,T), g (B,gin), noise (B,inter,T) -> (B,1,T*samples_per_frame) fp32."""
+        B, cu, T = unit.shape
+        mc = self.model_config
+        if cu != mc.get("unit_channels", 256) or g.shape != (B, mc["gin_channels"]) or \
+                tuple(noise.shape) != (B, mc["inter_channels"], T):
+            raise ValueError(f"bad input shapes: unit {tuple(unit.shape)}, g {tuple(g.shape)}, noise {tuple(noise.shape)}")
+        unit, g, noise = (self._f32(t, self.device) for t in (unit, g, noise))
+        if out is None:
+            out = torch.empty(B, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        st = self.lib.qvc_infer_batch(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
+                                      noise.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), ws.numel(), stream)
+        L.check(self.lib, st, "qvc_infer_batch")
+        return out
+
+    # ---- stage entry points (frame-major tensors), used by the stage-level parity tests
+    def enc_p(self, unit, noise):
+        B, _, T = unit.shape
+        unit, noise = self._f32(unit, self.device), self._f32(noise, self.device)
+        z = torch.empty(B, T, self.model_config["inter_channels"], dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T)
+        st = self.lib.qvc_enc_p(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), noise.data_ptr(),
+                                z.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
+                                torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_enc_p")
+        return z
+
+    def flow_reverse(self, z_fm, g):
+        B, T, _ = z_fm.shape
+        z = self._f32(z_fm, self.device).clone()
+        g = self._f32(g, self.device)
+        ws = self.workspace(B, T)
+        st = self.lib.qvc_flow_reverse(ctypes.byref(self.cfg), self.blob.data_ptr(), z.data_ptr(), g.data_ptr(), B, T,
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_flow_reverse")
+        return z
+
+    def dec_trunk(self, z_fm, g):
+        B, T, _ = z_fm.shape
+        z, g = self._f32(z_fm, self.device), self._f32(g, self.device)
+        frames = T * (self.samples_per_frame // (self.model_config["gen_istft_hop_size"] * self.model_config["subbands"])) + 1
+        pc = self.model_config["subbands"] * 2 * (self.model_config["gen_istft_n_fft"] // 2 + 1)
+        post = torch.empty(B, frames, pc, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T)
+        st = self.lib.qvc_dec_trunk(ctypes.byref(self.cfg), self.blob.data_ptr(), z.data_ptr(), g.data_ptr(),
+                                    post.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
+                                    torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_dec_trunk")
+        return post
+
+    def istft_synth(self, post_fm, want_bands: bool = False):
+        B, F, _ = post_fm.shape
+        post = self._f32(post_fm, self.device)
+        hop, sb = self.model_config["gen_istft_hop_size"], self.model_config["subbands"]
+        out = torch.empty(B, 1, sb * hop * (F - 1), dtype=torch.float32, device=self.device)
+        ymb = torch.empty(B, sb, hop * (F - 1), dtype=torch.float32, device=self.device) if want_bands else None
+        st = self.lib.qvc_istft_synth(ctypes.byref(self.cfg), self.blob.data_ptr(), post.data_ptr(), out.data_ptr(),
+                                      ymb.data_ptr() if want_bands else None, B, F,
+                                      torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_istft_synth")
+        return (out, ymb) if want_bands else out

@@ -1,0 +1,161 @@
+"""ctypes binding of libqvc_hip.so (include/qvc.h).  No torch types cross this boundary:
+only raw pointers (``tensor.data_ptr()``), sizes, the POD ``qvc_config`` and a stream handle.
+
+The library is looked up next to this file (built in-tree by build.py).  A missing library
+is a hard error: the product has no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict
+
+import torch
+
+QVC_OK = 0
+QVC_BF16, QVC_F16 = 0, 1
+QVC_DEC_ISTFT, QVC_DEC_MULTIBAND, QVC_DEC_MULTISTREAM = 0, 1, 2
+QVC_MAX_UPS = QVC_MAX_RESBLOCKS = 4
+DTYPES = {"bf16": QVC_BF16, "f16": QVC_F16, "fp16": QVC_F16}
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libqvc_hip.so")
+
+
+class QvcConfig(ctypes.Structure):
+    _fields_ = [
+        ("unit_channels", ctypes.c_int32), ("inter_channels", ctypes.c_int32), ("hidden_channels", ctypes.c_int32),
+        ("gin_channels", ctypes.c_int32), ("wn_kernel_size", ctypes.c_int32), ("enc_layers", ctypes.c_int32),
+        ("flow_layers", ctypes.c_int32), ("n_flows", ctypes.c_int32), ("upsample_initial_channel", ctypes.c_int32),
+        ("n_ups", ctypes.c_int32), ("upsample_rates", ctypes.c_int32 * QVC_MAX_UPS),
+        ("upsample_kernel_sizes", ctypes.c_int32 * QVC_MAX_UPS), ("n_resblocks", ctypes.c_int32),
+        ("resblock_kernel_sizes", ctypes.c_int32 * QVC_MAX_RESBLOCKS),
+        ("resblock_dilations", (ctypes.c_int32 * 3) * QVC_MAX_RESBLOCKS),
+        ("n_fft", ctypes.c_int32), ("hop", ctypes.c_int32), ("subbands", ctypes.c_int32), ("decoder", ctypes.c_int32),
+        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("precise_post", ctypes.c_int32),
+    ]
+
+
+class QvcTensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * 4)]
+
+
+class QvcError(RuntimeError):
+    pass
+
+
+def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
+    """Signatures of include/qvc.h (also used for the test-only emulation library)."""
+    P, I, L, V = ctypes.POINTER, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    cfgp = P(QvcConfig)
+    if prefix == "qvc":
+        lib.qvc_abi_version.restype = ctypes.c_int
+        lib.qvc_status_string.restype = ctypes.c_char_p
+        lib.qvc_status_string.argtypes = [ctypes.c_int]
+        lib.qvc_device_check.restype = ctypes.c_int
+        lib.qvc_blob_bytes.restype = L
+        lib.qvc_blob_bytes.argtypes = [cfgp]
+        lib.qvc_pack_weights.restype = ctypes.c_int
+        lib.qvc_pack_weights.argtypes = [cfgp, P(QvcTensor), I, V, L]
+        lib.qvc_workspace_bytes.restype = L
+        lib.qvc_workspace_bytes.argtypes = [cfgp, I, I]
+        lib.qvc_infer_batch.restype = ctypes.c_int
+        lib.qvc_infer_batch.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
+        lib.qvc_enc_p.restype = ctypes.c_int
+        lib.qvc_enc_p.argtypes = [cfgp, V, V, V, V, I, I, V, L, V]
+        lib.qvc_flow_reverse.restype = ctypes.c_int
+        lib.qvc_flow_reverse.argtypes = [cfgp, V, V, V, I, I, V, L, V]
+        lib.qvc_dec_trunk.restype = ctypes.c_int
+        lib.qvc_dec_trunk.argtypes = [cfgp, V, V, V, V, I, I, V, L, V]
+        lib.qvc_istft_synth.restype = ctypes.c_int
+        lib.qvc_istft_synth.argtypes = [cfgp, V, V, V, V, I, I, V]
+        lib.qvc_conv1d_scratch_bytes.restype = L
+        lib.qvc_conv1d_scratch_bytes.argtypes = [I, I, I]
+        lib.qvc_conv1d_workspace_bytes.restype = L
+        lib.qvc_conv1d_workspace_bytes.argtypes = [I, I, I, I]
+        lib.qvc_conv1d.restype = ctypes.c_int
+        lib.qvc_conv1d.argtypes = [V, V, V, V, I, I, I, I, I, I, ctypes.c_float, I, V, V, L, V, L, V]
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Loads libqvc_hip.so or raises -- never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise QvcError(f"{_LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                           "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
+        lib = ctypes.CDLL(_LIB_PATH)
+        declare(lib)
+        if lib.qvc_abi_version() != 1:
+            raise QvcError("libqvc_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(lib, status: int, what: str) -> None:
+    if status != QVC_OK:
+        raise QvcError(f"{what} failed: {lib.qvc_status_string(int(status)).decode()} ({status})")
+
+
+def make_config(mc: dict) -> QvcConfig:
+    """``SynthesizerTrn.model_config`` (models.py:551-591 hyper-parameters) -> qvc_config."""
+    c = QvcConfig()
+    c.unit_channels = int(mc.get("unit_channels", 256))
+    c.inter_channels, c.hidden_channels = int(mc["inter_channels"]), int(mc["hidden_channels"])
+    c.gin_channels = int(mc["gin_channels"])
+    c.wn_kernel_size, c.enc_layers, c.flow_layers, c.n_flows = 5, 16, 4, 4          # models.py:582-584
+    c.upsample_initial_channel = int(mc["upsample_initial_channel"])
+    ups, ks = list(mc["upsample_rates"]), list(mc["upsample_kernel_sizes"])
+    rk, rd = list(mc["resblock_kernel_sizes"]), [list(d) for d in mc["resblock_dilation_sizes"]]
+    if len(ups) > QVC_MAX_UPS or len(rk) > QVC_MAX_RESBLOCKS or len(ups) != len(ks) or len(rk) != len(rd):
+        raise QvcError("unsupported upsample / resblock configuration")
+    c.n_ups = len(ups)
+    for i, (u, k) in enumerate(zip(ups, ks)):
+        c.upsample_rates[i], c.upsample_kernel_sizes[i] = int(u), int(k)
+    c.n_resblocks = len(rk)
+    for j, (k, d) in enumerate(zip(rk, rd)):
+        if len(d) != 3:
+            raise QvcError("ResBlock1 needs three dilations")
+        c.resblock_kernel_sizes[j] = int(k)
+        for q in range(3):
+            c.resblock_dilations[j][q] = int(d[q])
+    c.n_fft, c.hop = int(mc["gen_istft_n_fft"]), int(mc["gen_istft_hop_size"])
+    c.subbands = int(mc["subbands"])
+    kind = mc.get("decoder", "multistream")
+    c.decoder = {"istft": QVC_DEC_ISTFT, "multiband": QVC_DEC_MULTIBAND, "multistream": QVC_DEC_MULTISTREAM}[kind]
+    c.fir_taps = 63
+    dt = mc.get("operand_dtype", "f16")
+    if dt not in DTYPES:
+        raise QvcError(f"operand_dtype must be one of {sorted(DTYPES)}")
+    c.operand_dtype = DTYPES[dt]
+    c.precise_post = 0
+    return c
+
+
+def pack_weights(lib, cfg: QvcConfig, state_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """state_dict (reference keys) -> packed host blob (uint8 tensor, 256-byte aligned storage)."""
+    n = int(lib.qvc_blob_bytes(ctypes.byref(cfg)))
+    if n < 0:
+        check(lib, n, "qvc_blob_bytes")
+    keep = []   # keep fp32 contiguous CPU copies alive during the call
+    arr = (QvcTensor * len(state_dict))()
+    i = 0
+    for name, t in state_dict.items():
+        if not torch.is_tensor(t) or not t.is_floating_point() or t.dim() > 4:
+            continue
+        tc = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        keep.append(tc)
+        arr[i].name = name.encode()
+        arr[i].data = tc.data_ptr()
+        arr[i].ndim = tc.dim()
+        for d in range(tc.dim()):
+            arr[i].shape[d] = tc.shape[d]
+        i += 1
+    raw = torch.empty(n + 256, dtype=torch.uint8)
+    shift = (-raw.data_ptr()) % 256
+    blob = raw[shift:shift + n]
+    check(lib, lib.qvc_pack_weights(ctypes.byref(cfg), arr, i, blob.data_ptr(), n), "qvc_pack_weights")
+    return blob

@@ -1,0 +1,65 @@
+"""Test-only loader for oracle/_build/libqvc_emu.so (host replay of the launch sequence)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def load_emu():
+    import importlib
+    build = importlib.import_module("quickvc_official_amd.build")
+    path = build.build_emu()
+    lib = ctypes.CDLL(path)
+    from quickvc_official_amd import lib as L
+    P, I, Lg, V = ctypes.POINTER, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    lib.qvc_emu_infer_batch.restype = ctypes.c_int
+    lib.qvc_emu_infer_batch.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, Lg]
+    lib.qvc_emu_tap_offset.restype = Lg
+    lib.qvc_emu_tap_offset.argtypes = [P(L.QvcConfig), I, I, I]
+    return lib
+
+
+def emu_infer(model_config, sd, unit, g, noise, dtype="f16", taps=None):
+    """Runs the emulated path on CPU. Returns (B,1,N) waveform; fills taps dict with workspace views."""
+    from quickvc_official_amd import lib as L
+    hip = L.load_library()          # host-only entry points (packer, size queries) work without a GPU
+    emu = load_emu()
+    mc = dict(model_config, operand_dtype=dtype)
+    cfg = L.make_config(mc)
+    blob = L.pack_weights(hip, cfg, sd)
+    B, _, T = unit.shape
+    n_ws = int(hip.qvc_workspace_bytes(ctypes.byref(cfg), B, T))
+    raw = torch.zeros(n_ws + 256, dtype=torch.uint8)
+    shift = (-raw.data_ptr()) % 256
+    ws = raw[shift:shift + n_ws]
+    spf = mc["gen_istft_hop_size"] * mc["subbands"]
+    for u in mc["upsample_rates"]:
+        spf *= u
+    out = torch.empty(B, 1, T * spf)
+    unit, g, noise = unit.float().contiguous(), g.float().contiguous(), noise.float().contiguous()
+    st = emu.qvc_emu_infer_batch(ctypes.byref(cfg), blob.data_ptr(), unit.data_ptr(), g.data_ptr(), noise.data_ptr(),
+                                 out.data_ptr(), B, T, ws.data_ptr(), n_ws)
+    assert st == 0, hip.qvc_status_string(st)
+    if taps is not None:
+        C = mc["inter_channels"]
+        off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 0)
+        taps["z"] = ws[off:off + B * T * C * 4].view(torch.float32).reshape(B, T, C).clone()
+        tu = 1
+        for u in mc["upsample_rates"]:
+            tu *= u
+        F = T * tu + 1
+        off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 1)
+        taps["post"] = ws[off:off + B * F * 72 * 4].view(torch.float32).reshape(B, F, 72).clone()
+        off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 5)
+        taps["stats"] = ws[off:off + B * T * 2 * C * 4].view(torch.float32).reshape(B, T, 2 * C).clone()
+        ch0 = mc["upsample_initial_channel"] // 2
+        t1 = T * mc["upsample_rates"][0]
+        off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 4)
+        taps["ups0"] = ws[off:off + B * t1 * ch0 * 4].view(torch.float32).reshape(B, t1, ch0).clone()
+        off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 2)
+        taps["mrf0"] = ws[off:off + B * t1 * ch0 * 4].view(torch.float32).reshape(B, t1, ch0).clone()
+    return out
