@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the QuickVC hot path on MI355X (BASELINE.json).
+
+Metric: audio samples/s (+ RTF) for offline voice conversion of 16 kHz 5 s utterances,
+batch 32 per GPU (BASELINE.json configs[2]; weak scaling: every rank converts its own
+batch, no per-step collective -- the only collective is one weight broadcast at start-up).
+
+One "step" = one pass of the whole hot path (enc_p -> reverse flow -> generator -> iSTFT +
+band synthesis) over one batch of 32 synthetic utterances already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task description) including
+  "roofline":     the dominant kernel's achieved TFLOP/s vs the gfx950 dense f16/bf16 MFMA peak,
+                  from per-launch HIP events (qvc_infer_batch_timed) on the launch stream;
+  "cpu_baseline": the fp32 CPU oracle (a port of the reference path) timed on this host's
+                  cores on a bounded sample of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLE_RATE = 16000
+FRAMES = 250            # 5 s of 320-sample unit frames
+BATCH = 32
+PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import quickvc_official_amd as q
+    from quickvc_official_amd import dist as qd
+    from quickvc_official_amd.engine import QvcEngine
+    from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_inputs
+
+    rank, local_rank, world = qd.env_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = dict(q.DEFAULT_MODEL_CONFIG)
+    model = q.SynthesizerTrn(641, 32, **cfg, operand_dtype=args.dtype)
+    # rank 0 owns the checkpoint; everybody else receives the packed blob in ONE broadcast
+    sd = make_synthetic_state_dict(model, 1234)
+    engine = QvcEngine(model.model_config, sd, device)       # every rank packs the same seed; then overwritten:
+    if world > 1:
+        qd.broadcast_blob(engine.blob, src=0)                 # RCCL over xGMI, once
+    B = args.batch
+    unit, g, noise = make_synthetic_inputs(B, FRAMES, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=rank * B)
+    unit, g, noise = unit.to(device), g.to(device), noise.to(device)
+    out = torch.empty(B, 1, FRAMES * engine.samples_per_frame, dtype=torch.float32, device=device)
+
+    # ---- one step, optionally as a hipGraph (the library call is capturable: no sync/alloc inside)
+    stream = torch.cuda.Stream(device)
+    graph = None
+    with torch.cuda.stream(stream):
+        engine.infer_batch(unit, g, noise, out)              # allocates workspace, loads code objects
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                engine.infer_batch(unit, g, noise, out)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            engine.infer_batch(unit, g, noise, out)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    wall = qd.max_over_ranks(wall, device)
+    samples_per_step = world * B * FRAMES * engine.samples_per_frame
+    value = samples_per_step * args.steps / wall
+    ms_per_step = wall / args.steps * 1e3
+
+    result = {
+        "metric": "audio samples/sec (16 kHz, 5 s utterances, batch 32 per GPU, whole hot path)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "batch=32 offline VC, 5 s 16 kHz utterances, 1xMI355X per rank (BASELINE.json configs[2])",
+                   "batch_per_gpu": B, "frames": FRAMES, "samples_per_utterance": FRAMES * engine.samples_per_frame,
+                   "operands": f"{args.dtype} MFMA operands, fp32 accumulate/residuals", "hipgraph": graph is not None,
+                   "parallelism": f"utterance-sharded x{world}, no per-step collective"},
+        "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
+    }
+
+    if rank == 0:
+        # ---- roofline leg: per-launch HIP events on the launch stream, same workload
+        with torch.cuda.stream(stream):
+            agg = {}
+            reps = 5
+            total_ms = 0.0
+            for _ in range(reps):
+                _, recs = engine.infer_batch_timed(unit, g, noise, out)
+                for r in recs:
+                    a = agg.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                    a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
+                    total_ms += r["ms"]
+        dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        all_flops = sum(a["flops"] for a in agg.values()) / reps
+        result["roofline"] = {
+            "bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": traffic,
+            "launches_per_step": dom["launches"] // reps, "avg_launch_ms": dom["ms"] / dom["launches"],
+            "kernel_share_of_step": dom["ms"] / total_ms,
+            "whole_step": {"flops": all_flops, "tflops": all_flops / (ms_per_step * 1e-3) / 1e12,
+                           "frac_mfma": all_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                           "event_sum_ms": total_ms / reps},
+            "by_kernel": {k: {"ms_per_step": v["ms"] / reps, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
+                              "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0,
+                              "launches": v["launches"] // reps} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+
+        # ---- parity + CPU baseline on a bounded sample of the same workload (oracle = checker / baseline only)
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import qvc_oracle as oracle
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(avail, 16)          # the 1-GPU box's CPU share; more threads only oversubscribe
+            torch.set_num_threads(cores)
+            n_cpu = 8
+            u_c, g_c, n_c = unit[:n_cpu].cpu(), g[:n_cpu].cpu(), noise[:n_cpu].cpu()
+            oracle.infer_from_g(sd, cfg, u_c[:1], g_c[:1].unsqueeze(-1), n_c[:1])          # warm-up
+            t0 = time.perf_counter()
+            ref = oracle.infer_from_g(sd, cfg, u_c, g_c.unsqueeze(-1), n_c)
+            cpu_wall = time.perf_counter() - t0
+            snrs = [oracle.snr_db(ref[i], out[i].cpu()) for i in range(n_cpu)]
+            result["cpu_baseline"] = {
+                "value": n_cpu * FRAMES * engine.samples_per_frame / cpu_wall, "unit": "samples/s", "cores": cores,
+                "kind": "port", "sample": f"{n_cpu} of the {B} utterances (5 s each), fp32 CPU oracle, 1 warm-up + 1 timed pass",
+                "wall_s": cpu_wall}
+            result["parity"] = {"snr_db_min": min(snrs), "snr_db_mean": sum(snrs) / len(snrs),
+                                "linf": float((ref - out[:n_cpu].cpu()).abs().max()), "tolerance_db": 40.0,
+                                "checked_utterances": n_cpu}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

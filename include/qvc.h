@@ -133,6 +133,25 @@ int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev,
                     int32_t batch, int32_t frames,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- the same call with per-launch timing (diagnostics for bench.py's roofline leg) ----
+ * Runs the identical launch sequence but brackets every launch with HIP events recorded on
+ * `stream`, synchronises the stream at the end and fills `records` (at most max_records;
+ * *n_records receives the number of launches).  Creates/destroys events, so unlike
+ * qvc_infer_batch it is NOT hipGraph-capturable and must not be used in the timed region.
+ */
+typedef struct qvc_launch_record {
+  char name[48];        /* e.g. "conv<f16,MF2,NF10,std>", "istft_synth", "cond_gemv", "memset" */
+  float ms;             /* device time of this launch (HIP events on the stream)                */
+  double flops;         /* algorithmic FLOPs (2*MAC) of the launch, 0 for byte movers           */
+  double bytes;         /* algorithmic bytes: activations in + out + weights, each counted once */
+} qvc_launch_record;
+
+int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev,
+                          const float* unit, const float* g, const float* noise, float* out,
+                          int32_t batch, int32_t frames,
+                          void* workspace, int64_t workspace_bytes, void* stream,
+                          qvc_launch_record* records, int32_t max_records, int32_t* n_records);
+
 /* ---- stages (same workspace; for stage-level parity tests and profiling) ------
  * Frame-major fp32 tensors: z_p / z are [B][T][inter_channels].
  */

@@ -4,7 +4,9 @@
 // allocation, no synchronisation, no host read of device data, so a whole qvc_infer_batch
 // call can be captured into a hipGraph by the caller.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 #include "qvc_path.h"
 #include "qvc_pack_util.h"
 
@@ -24,6 +26,60 @@ struct HipBackend {
   int zero(void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; }
 };
 using Ctx = Path<HipBackend>;
+
+// Same launches, each bracketed by events on the stream (diagnostics only).
+struct TimedBackend {
+  hipStream_t stream;
+  qvc_launch_record* rec; int max_rec; int n = 0;
+  std::vector<hipEvent_t> ev;
+  bool ok = true;
+  void mark() { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, stream) != hipSuccess) ok = false; ev.push_back(e); }
+  void note(const char* name, double flops, double bytes) {
+    if (n < max_rec) { std::snprintf(rec[n].name, sizeof(rec[n].name), "%s", name); rec[n].flops = flops; rec[n].bytes = bytes; rec[n].ms = 0.f; }
+    ++n;
+  }
+  int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) {
+    if (ev.empty()) mark();
+    int nf = 0;
+    int st = launch_conv(d, a, batch, epi, dtype, stream, &nf);
+    mark();
+    char name[48];
+    std::snprintf(name, sizeof(name), "conv<%s,MF%d,NF%d,%s>", dtype == QVC_F16 ? "f16" : "bf16", d.MF, nf, epi == EPI_GAU ? "gau" : "std");
+    // algorithmic work: a transposed conv does k MACs per (input frame, ci, co), a conv taps MACs per output
+    const double macs = d.up_s > 1 ? (double)batch * a.T_in * d.Cin * d.Cout * (double)d.ksize
+                                   : (double)batch * a.Nq * (double)d.M * d.taps * d.Cin;
+    const double in_b = (double)batch * a.T_in * d.Cin * (a.x_kind == XK_OP_FM ? 2 : 4);
+    double out_b = 0;
+    const double outs = (double)batch * a.T_out * d.Cout;
+    if (epi == EPI_GAU) out_b = (double)batch * a.Nq * a.gau_H * 2;
+    else {
+      if (a.y32) out_b += outs * 4 * (a.y_accum ? 2 : 1);
+      if (a.y16) out_b += outs * 2;
+      if (a.res) out_b += outs * 4;
+      if (a.y32b) out_b += (double)batch * a.Nq * (d.M - a.split) * 8;
+    }
+    note(name, 2.0 * macs, in_b + out_b + (double)d.w_bytes());
+    return st;
+  }
+  int gemv(const GemvArgs& a) { if (ev.empty()) mark(); int st = launch_gemv(a, stream); mark();
+    note("cond_gemv", 2.0 * a.rows * a.gin * a.batch, (double)a.rows * a.gin * 4 + (double)a.batch * (a.rows + a.gin) * 4); return st; }
+  int sample(const SampleArgs& a) { if (ev.empty()) mark(); int st = launch_sample(a, stream); mark();
+    note("sample", 0, (double)a.batch * a.frames * a.C * 16); return st; }
+  int tail(const TailArgs& a) { if (ev.empty()) mark(); int st = launch_tail(a, stream); mark();
+    note("istft_synth", 0, (double)a.batch * ((double)a.F * 72 * 4 + 16.0 * (a.F - 1) * 4)); return st; }
+  int zero(void* p, size_t bytes) { if (ev.empty()) mark(); int st = hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; mark();
+    note("memset", 0, (double)bytes); return st; }
+  int finish() {
+    if (!ok || hipStreamSynchronize(stream) != hipSuccess) ok = false;
+    for (int i = 0; i + 1 < (int)ev.size() && i < max_rec; ++i) {
+      float ms = 0.f;
+      if (ok && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) rec[i].ms = ms;
+    }
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+    ev.clear();
+    return ok ? QVC_OK : QVC_ERR_LAUNCH;
+  }
+};
 
 int check_common(const qvc_config* cfg, const void* blob, int batch, int frames, void* ws, int64_t ws_bytes, Plan& P,
                  Workspace& W) {
@@ -88,6 +144,26 @@ int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev, const float* un
   c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
   c.tail(c.wsp<float>(W.post), out, nullptr, frames * P.total_up + 1);
   return c.status;
+}
+
+int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,
+                          const float* noise, float* out, int32_t batch, int32_t frames, void* workspace,
+                          int64_t workspace_bytes, void* stream, qvc_launch_record* records, int32_t max_records,
+                          int32_t* n_records) {
+  if (!unit || !g || !noise || !out || !records || max_records <= 0 || !n_records) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  TimedBackend be{static_cast<hipStream_t>(stream), records, max_records};
+  Path<TimedBackend> c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.cond_table(g);
+  c.enc_p(unit, noise, c.wsp<float>(W.z));
+  c.flow(c.wsp<float>(W.z));
+  c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
+  c.tail(c.wsp<float>(W.post), out, nullptr, frames * P.total_up + 1);
+  const int fin = be.finish();
+  *n_records = be.n;
+  return c.status != QVC_OK ? c.status : fin;
 }
 
 int qvc_enc_p(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* noise, float* z_p_fm,

@@ -273,9 +273,10 @@ inline int launch_one(const ConvArgs& a, int batch, int Nq, size_t lds, hipStrea
 }
 
 template <typename T, int MF, int EPI>
-inline int launch_nf(const ConvDesc& d, const ConvArgs& a, int batch, hipStream_t stream) {
+inline int launch_nf(const ConvDesc& d, const ConvArgs& a, int batch, hipStream_t stream, int* nf_out) {
   static const int nfs[] = {2, 4, 5, 8, 10};
   const TileChoice tc = choose_tile(d, a.Nq, batch, EPI, nfs, 5);
+  if (nf_out) *nf_out = tc.NF;
   switch (tc.NF) {
     case 2: return launch_one<T, MF, 2, EPI>(a, batch, a.Nq, tc.lds, stream);
     case 4: return launch_one<T, MF, 4, EPI>(a, batch, a.Nq, tc.lds, stream);
@@ -289,17 +290,17 @@ inline int launch_nf(const ConvDesc& d, const ConvArgs& a, int batch, hipStream_
 }
 
 template <typename T>
-int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream_v) {
+int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream_v, int* nf_out) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (epi == EPI_GAU) {
     if (d.MF != 2) return QVC_ERR_BAD_CONFIG;
-    return launch_nf<T, 2, EPI_GAU>(d, a, batch, stream);
+    return launch_nf<T, 2, EPI_GAU>(d, a, batch, stream, nf_out);
   }
   switch (d.MF) {
-    case 1: return launch_nf<T, 1, EPI_STD>(d, a, batch, stream);
-    case 2: return launch_nf<T, 2, EPI_STD>(d, a, batch, stream);
-    case 3: return launch_nf<T, 3, EPI_STD>(d, a, batch, stream);
-    case 4: return launch_nf<T, 4, EPI_STD>(d, a, batch, stream);
+    case 1: return launch_nf<T, 1, EPI_STD>(d, a, batch, stream, nf_out);
+    case 2: return launch_nf<T, 2, EPI_STD>(d, a, batch, stream, nf_out);
+    case 3: return launch_nf<T, 3, EPI_STD>(d, a, batch, stream, nf_out);
+    case 4: return launch_nf<T, 4, EPI_STD>(d, a, batch, stream, nf_out);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }

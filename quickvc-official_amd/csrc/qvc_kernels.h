@@ -57,15 +57,13 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
   int32_t batch, F;
 };
 
-struct DeviceInfo { int cus = 256; int lds_per_cu = 160 * 1024; };
-
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
-int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream);
+int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
 int launch_gemv(const GemvArgs& a, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
 int launch_tail(const TailArgs& a, void* stream);
 
 // Instantiation entry (one translation unit per operand dtype).
-template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream);
+template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
 
 }  // namespace qvc

@@ -31,6 +31,7 @@ struct ConvDesc {
   int32_t taps = 1, dil = 1, left = 0;
   int32_t up_s = 1, up_p = 0;   // polyphase: stride / padding of the ConvTranspose1d (1/0: plain conv)
   int32_t Cout = 0;     // real output channels (M = up_s * Cout)
+  int32_t ksize = 1;    // kernel size of the original (transposed) conv, for FLOP accounting
   int32_t gau = 0;      // 1: rows permuted so that a wave owns tanh and sigmoid rows of the same channels
   int64_t w_off = 0;    // byte offset of the A stream
   int64_t b_off = 0;    // byte offset of the fp32 bias [MP]
@@ -141,7 +142,7 @@ inline int validate(const qvc_config& c) {
 inline ConvDesc make_conv(int M, int Cin, int taps, int dil, bool gau = false) {
   ConvDesc d;
   d.M = M; d.Cout = M; d.Cin = Cin; d.CinP = (int)align_up(Cin, kKStep);
-  d.taps = taps; d.dil = dil; d.left = (taps - 1) / 2 * dil; d.gau = gau ? 1 : 0;
+  d.taps = taps; d.ksize = taps; d.dil = dil; d.left = (taps - 1) / 2 * dil; d.gau = gau ? 1 : 0;
   choose_mf(d);
   return d;
 }
@@ -150,7 +151,7 @@ inline ConvDesc make_upconv(int Cin, int Cout, int k, int s, int p) {
   ConvDesc d;
   d.up_s = s; d.up_p = p; d.Cout = Cout; d.M = s * Cout;
   d.Cin = Cin; d.CinP = (int)align_up(Cin, kKStep);
-  d.taps = ceil_div(k, s); d.dil = 1; d.left = d.taps - 1;
+  d.taps = ceil_div(k, s); d.ksize = k; d.dil = 1; d.left = d.taps - 1;
   choose_mf(d);
   return d;
 }

@@ -78,6 +78,23 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_infer_batch")
         return out
 
+    def infer_batch_timed(self, unit, g, noise, out=None, max_records: int = 512):
+        """Same launches with per-launch HIP-event timing; returns (out, [dict(name, ms, flops, bytes)])."""
+        B, _, T = unit.shape
+        unit, g, noise = (self._f32(t, self.device) for t in (unit, g, noise))
+        if out is None:
+            out = torch.empty(B, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T)
+        rec = (L.QvcLaunchRecord * max_records)()
+        n = ctypes.c_int32(0)
+        st = self.lib.qvc_infer_batch_timed(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
+                                            noise.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream(self.device).cuda_stream, rec, max_records,
+                                            ctypes.byref(n))
+        L.check(self.lib, st, "qvc_infer_batch_timed")
+        return out, [dict(name=rec[i].name.decode(), ms=float(rec[i].ms), flops=float(rec[i].flops),
+                          bytes=float(rec[i].bytes)) for i in range(min(n.value, max_records))]
+
     # ---- stage entry points (frame-major tensors), used by the stage-level parity tests
     def enc_p(self, unit, noise):
         B, _, T = unit.shape

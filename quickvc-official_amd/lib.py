@@ -40,6 +40,11 @@ class QvcTensor(ctypes.Structure):
                 ("shape", ctypes.c_int64 * 4)]
 
 
+class QvcLaunchRecord(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("ms", ctypes.c_float), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double)]
+
+
 class QvcError(RuntimeError):
     pass
 
@@ -61,6 +66,8 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_workspace_bytes.argtypes = [cfgp, I, I]
         lib.qvc_infer_batch.restype = ctypes.c_int
         lib.qvc_infer_batch.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
+        lib.qvc_infer_batch_timed.restype = ctypes.c_int
+        lib.qvc_infer_batch_timed.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V, P(QvcLaunchRecord), I, P(I)]
         lib.qvc_enc_p.restype = ctypes.c_int
         lib.qvc_enc_p.argtypes = [cfgp, V, V, V, V, I, I, V, L, V]
         lib.qvc_flow_reverse.restype = ctypes.c_int

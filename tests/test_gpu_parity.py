@@ -1,0 +1,222 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle and against the golden vectors recorded from the reference.
+
+Tolerances (floating point, stated here as the task requires):
+  * one conv through the MFMA kernel vs the same conv in fp64 on operands rounded to the MFMA
+    operand type: max abs error <= 2e-5 * (1 + |y|max)  (fp32 accumulation order only);
+  * whole path, f16 operands: waveform SNR >= 45 dB per utterance (target of BASELINE.json: 40 dB;
+    measured ~52.6 dB); bf16 operands: >= 30 dB (measured ~34.5 dB -- documented as NOT meeting
+    the 40 dB bar, which is why f16 is the default operand type);
+  * fp32 tail (iSTFT + synthesis FIR): SNR >= 100 dB.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import qvc_oracle as oracle
+from helpers import load_case, regenerate, snr_db
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from quickvc_official_amd import lib as L
+    l = L.load_library()                       # raises if the HIP library is missing: no fallback
+    assert l.qvc_device_check() == 0
+    return l
+
+
+def _engine(entry, sd, dev, dtype):
+    import quickvc_official_amd as q
+    from quickvc_official_amd.engine import QvcEngine
+    model = q.SynthesizerTrn(641, 32, **entry["config"])
+    return QvcEngine(dict(model.model_config, operand_dtype=dtype), sd, dev)
+
+
+def _fm(t):
+    return t.transpose(1, 2).contiguous()
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, k, dil, slope
+    (1, 32, 64, 40, 1, 1, 1.0),
+    (2, 64, 64, 37, 3, 1, 0.1),
+    (2, 128, 128, 300, 11, 5, 0.1),
+    (2, 256, 256, 200, 7, 3, 0.1),
+    (1, 192, 384, 250, 5, 1, 1.0),
+    (2, 128, 72, 130, 7, 1, 0.01),
+    (3, 40, 80, 21, 5, 1, 1.0),
+    (1, 512, 128, 1, 1, 1, 1.0),      # single frame
+    (1, 8, 4, 700, 3, 1, 0.1),        # smallest legal channel counts, many tiles
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_kernel_vs_rounded_reference(lib, dev, case, dtype):
+    from quickvc_official_amd import lib as L
+    B, cin, cout, T, k, dil, slope = case
+    gen = torch.Generator().manual_seed(cin * 7 + cout + k + dil)
+    x = torch.randn(B, cin, T, generator=gen)
+    w = torch.randn(cout, cin, k, generator=gen) / (cin * k) ** 0.5
+    bias = torch.randn(cout, generator=gen) * 0.1
+    nb = int(lib.qvc_conv1d_scratch_bytes(cout, cin, k))
+    nw = int(lib.qvc_conv1d_workspace_bytes(B, cout, cin, T))
+    assert nb > 0 and nw > 0
+    sh = torch.empty(nb + 256, dtype=torch.uint8)
+    sd_ = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+    ws = torch.empty(nw + 256, dtype=torch.uint8, device=dev)
+    al = lambda t: t.data_ptr() + ((-t.data_ptr()) % 256)
+    xd = x.to(dev)
+    y = torch.full((B, cout, T), float("nan"), device=dev)
+    st = lib.qvc_conv1d(xd.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), B, cin, cout, T, k, dil, slope,
+                        L.DTYPES[dtype], al(sh), al(sd_), nb, al(ws), nw, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert st == 0
+    td = torch.float16 if dtype == "f16" else torch.bfloat16
+    xr = F.leaky_relu(x, slope).to(td).double()
+    wr = w.to(td).double()
+    ref = F.conv1d(xr, wr, bias.double(), padding=(k - 1) // 2 * dil, dilation=dil).float()
+    err = float((ref - y.cpu()).abs().max())
+    assert err <= 2e-5 * (1.0 + float(ref.abs().max())), err
+
+
+def test_conv_entry_point_rejects_bad_arguments(lib, dev):
+    assert lib.qvc_conv1d_scratch_bytes(10, 16, 3) == -1          # Cout % 4
+    assert lib.qvc_conv1d_scratch_bytes(16, 12, 3) == -1          # Cin % 8
+    assert lib.qvc_conv1d(None, None, None, None, 1, 8, 4, 8, 3, 1, 1.0, 1, None, None, 0, None, 0, None) == -1
+
+
+@pytest.mark.parametrize("name,dtype,min_db", [
+    ("mini", "f16", 45.0), ("odd", "f16", 45.0), ("mini_t37", "f16", 45.0), ("mini_mb", "f16", 45.0),
+    ("mini", "bf16", 30.0), ("odd", "bf16", 30.0),
+])
+def test_stages_and_whole_path_vs_oracle_and_golden(lib, dev, name, dtype, min_db):
+    entry, gold = load_case(name)
+    _m, sd, unit, g, noise = regenerate(entry)
+    taps = {}
+    ref = oracle.infer_from_g(sd, entry["config"], unit, g.unsqueeze(-1), noise, taps)
+    eng = _engine(entry, sd, dev, dtype)
+    # stage by stage, each fed with the oracle's input for that stage
+    z_p = eng.enc_p(unit, noise)
+    assert snr_db(_fm(taps["enc_p.z_p"]), z_p.cpu()) >= min_db + 5
+    z = eng.flow_reverse(_fm(taps["enc_p.z_p"]), g)
+    assert snr_db(_fm(taps["flow.flows.0.out"]), z.cpu()) >= min_db + 5
+    post = eng.dec_trunk(_fm(taps["flow.flows.0.out"]), g)
+    assert snr_db(_fm(taps["dec.subband_conv_post"]), post.cpu()) >= min_db + 5
+    out, ymb = eng.istft_synth(_fm(taps["dec.subband_conv_post"]), want_bands=True)
+    assert snr_db(ref, out.cpu()) >= 100.0                                   # fp32 tail
+    assert snr_db(taps["dec.y_mb"], ymb.cpu()) >= 100.0
+    # whole path vs oracle and vs the reference's own output
+    full = eng.infer_batch(unit.to(dev), g.to(dev), noise.to(dev))
+    torch.cuda.synchronize()
+    assert full.shape == (entry["batch"], 1, 320 * entry["frames"])         # length rule
+    for b in range(entry["batch"]):
+        assert snr_db(ref[b], full[b].cpu()) >= min_db
+    assert snr_db(gold["o"], full.cpu().reshape(-1).numpy()) >= min_db
+
+
+@pytest.mark.parametrize("name", ["full_b1", "full_b2"])
+def test_full_config_vs_reference_golden(lib, dev, name):
+    """Shipped config, T=250: output vs the waveform the reference produced (>= 45 dB, f16)."""
+    entry, gold = load_case(name)
+    _m, sd, unit, g, noise = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    full = eng.infer_batch(unit.to(dev), g.to(dev), noise.to(dev))
+    torch.cuda.synchronize()
+    want = gold["o"].reshape(entry["batch"], -1)
+    for b in range(entry["batch"]):
+        assert snr_db(want[b], full[b].cpu().reshape(-1).numpy()) >= 45.0
+    assert float(np.abs(want - full.cpu().reshape(entry["batch"], -1).numpy()).max()) < 0.05
+
+
+def test_batch32_properties_at_benchmark_size(lib, dev):
+    """BASELINE size (B=32, T=250): size-independent properties instead of a full oracle run.
+    (1) batch independence: utterance b of the batch == the same utterance converted alone
+        (different tiles are picked for B=1, the K order is the same -> bit-identical);
+    (2) determinism across two runs; (3) finite output of the right length;
+    (4) three utterances spot-checked against the oracle."""
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    unit, g, noise = make_synthetic_inputs(32, 250, 256, 192, 256, seed0=100)
+    ud, gd, nd = unit.to(dev), g.to(dev), noise.to(dev)
+    out = eng.infer_batch(ud, gd, nd).clone()
+    out2 = eng.infer_batch(ud, gd, nd).clone()
+    torch.cuda.synchronize()
+    assert out.shape == (32, 1, 80000) and bool(torch.isfinite(out).all())
+    assert torch.equal(out, out2)
+    for b in (0, 17, 31):
+        alone = eng.infer_batch(ud[b:b + 1], gd[b:b + 1], nd[b:b + 1])
+        torch.cuda.synchronize()
+        assert snr_db(out[b].cpu(), alone[0].cpu()) >= 100.0
+        ref = oracle.infer_from_g(sd, entry["config"], unit[b:b + 1], g[b:b + 1].unsqueeze(-1), noise[b:b + 1])
+        assert snr_db(ref[0], out[b].cpu()) >= 45.0
+
+
+def test_infer_api_matches_reference_semantics(lib, dev):
+    """SynthesizerTrn.infer(unit, mel): speaker encoder (PyTorch) + HIP path, vs the golden infer() output."""
+    import os
+    import quickvc_official_amd as q
+    from quickvc_official_amd.synth import make_synthetic_mel
+    import helpers
+    entry, _ = load_case("mini")
+    spk = dict(np.load(os.path.join(helpers.GOLDEN, "mini_spk.npz")))
+    model, sd, unit, g, noise = regenerate(entry)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    mel = make_synthetic_mel(300, 80, seed=307)
+    o = model.infer(unit[:1].cuda(), mel.cuda(), noise=noise[:1].cuda())
+    torch.cuda.synchronize()
+    assert o.shape == (1, 1, 320 * entry["frames"]) and o.dtype == torch.float32
+    assert snr_db(spk["infer_o"], o.cpu().numpy()) >= 45.0
+    # a weight reload must invalidate the packed blob
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["dec.multistream_conv_post.weight_g"] = sd2["dec.multistream_conv_post.weight_g"] * 2.0
+    model.load_state_dict(sd2)
+    o2 = model.infer(unit[:1].cuda(), mel.cuda(), noise=noise[:1].cuda())
+    assert snr_db(2.0 * spk["infer_o"], o2.cpu().numpy()) >= 45.0
+
+
+def test_hipgraph_capture_replays_identically(lib, dev):
+    entry, _ = load_case("mini_t37")
+    _m, sd, unit, g, noise = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    ud, gd, nd = unit.to(dev), g.to(dev), noise.to(dev)
+    out = torch.empty(entry["batch"], 1, 320 * entry["frames"], device=dev)
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        eager = eng.infer_batch(ud, gd, nd).clone()
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            eng.infer_batch(ud, gd, nd, out)
+        out.zero_()
+        graph.replay()
+        s.synchronize()
+    assert torch.equal(out, eager)
+
+
+def test_timed_variant_reports_every_launch(lib, dev):
+    entry, _ = load_case("mini")
+    _m, sd, unit, g, noise = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    out, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
+    ref = eng.infer_batch(unit.to(dev), g.to(dev), noise.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    names = [r["name"] for r in recs]
+    assert names.count("istft_synth") == 1 and names.count("cond_gemv") == 1
+    assert sum(n.startswith("conv<") for n in names) == 1 + 32 + 1 + 4 * (2 + 8) + 1 + 2 * (1 + 18) + 1
+    assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0

@@ -1,0 +1,179 @@
+"""CPU tests (no GPU): C-ABI surface, packer errors, host emulation of the launch sequence vs the
+oracle, config / checkpoint drop-in behaviour, and the multi-process sharding logic (gloo)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import qvc_oracle as oracle
+from helpers import ROOT, load_case, regenerate, snr_db
+
+
+@pytest.fixture(scope="module")
+def built():
+    """Build (or reuse) the product library and the test-only emulation; host entry points only."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build()
+    from quickvc_official_amd import lib as L
+    return L.load_library()
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "qvc.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 14
+    for n in sorted(names):
+        assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
+    assert built.qvc_abi_version() == 1
+    assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
+
+
+def test_package_fails_loudly_without_gpu_or_library(built, monkeypatch):
+    import quickvc_official_amd as q
+    from quickvc_official_amd import lib as L
+    model = q.SynthesizerTrn(641, 32, **q.MINI_MODEL_CONFIG)
+    unit = torch.zeros(1, 256, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.infer_batch(unit, torch.zeros(1, 64))
+    monkeypatch.setattr(L, "_LIB_PATH", "/nonexistent/libqvc_hip.so")
+    monkeypatch.setattr(L, "_lib", None)
+    with pytest.raises(L.QvcError, match="missing"):
+        L.load_library()
+
+
+def test_pack_weights_error_codes(built):
+    import quickvc_official_amd as q
+    from quickvc_official_amd import lib as L
+    from quickvc_official_amd.synth import make_synthetic_state_dict
+    model = q.SynthesizerTrn(641, 32, **q.MINI_MODEL_CONFIG)
+    sd = make_synthetic_state_dict(model, 1)
+    cfg = L.make_config(model.model_config)
+    blob = L.pack_weights(built, cfg, sd)
+    assert blob.numel() == built.qvc_blob_bytes(ctypes.byref(cfg)) and blob.data_ptr() % 256 == 0
+    # enc_q and enc_spk are not on the path: packing must not need them (tolerant like utils.load_checkpoint)
+    small = {k: v for k, v in sd.items() if not k.startswith(("enc_q.", "enc_spk."))}
+    assert torch.equal(L.pack_weights(built, cfg, small), blob)
+    missing = {k: v for k, v in sd.items() if k != "flow.flows.2.post.weight"}
+    with pytest.raises(L.QvcError, match="missing"):
+        L.pack_weights(built, cfg, missing)
+    bad = dict(sd); bad["dec.conv_pre.weight_v"] = sd["dec.conv_pre.weight_v"][:, :-1]
+    with pytest.raises(L.QvcError, match="shape"):
+        L.pack_weights(built, cfg, bad)
+    cfg2 = L.make_config(dict(model.model_config)); cfg2.n_flows = 3
+    assert built.qvc_blob_bytes(ctypes.byref(cfg2)) == -2
+    cfg3 = L.make_config(dict(model.model_config)); cfg3.inter_channels = 50
+    assert built.qvc_workspace_bytes(ctypes.byref(cfg3), 1, 10) == -2
+    assert built.qvc_workspace_bytes(ctypes.byref(cfg), 0, 10) == -1
+
+
+def test_weight_norm_and_flip_folding_change_nothing(built):
+    """Packing the same effective weights from weight_g/weight_v pairs or from pre-folded plain weights
+    gives the identical blob (the fold is exact in fp32 before the operand conversion)."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd import lib as L
+    from quickvc_official_amd.synth import make_synthetic_state_dict
+    model = q.SynthesizerTrn(641, 32, **q.MINI_MODEL_CONFIG)
+    sd = make_synthetic_state_dict(model, 5)
+    cfg = L.make_config(model.model_config)
+    a = L.pack_weights(built, cfg, sd)
+    scaled = dict(sd)
+    for k in sd:                       # w = g*v/|v| is invariant to a rescale of v
+        if k.endswith(".weight_v") and k.startswith(("dec.resblocks.0", "enc_p.enc.in_layers.3")):
+            scaled[k] = sd[k] * 4.0    # power of two: exact
+    assert torch.equal(L.pack_weights(built, cfg, scaled), a)
+
+
+@pytest.mark.parametrize("name,dtype,min_db", [("mini", "f16", 50.0), ("odd", "f16", 50.0), ("mini_mb", "f16", 50.0),
+                                               ("mini", "bf16", 32.0)])
+def test_host_emulation_of_launch_sequence_matches_oracle(built, name, dtype, min_db):
+    """The product's launch sequence + packed blob, replayed on the CPU by oracle/qvc_emu.cpp."""
+    from emu import emu_infer
+    entry, gold = load_case(name)
+    model, sd, unit, g, noise = regenerate(entry)
+    ref = oracle.infer_from_g(sd, entry["config"], unit, g.unsqueeze(-1), noise)
+    out = emu_infer(model.model_config, sd, unit, g, noise, dtype)
+    assert out.shape == ref.shape
+    assert snr_db(ref, out) >= min_db
+    assert snr_db(gold["o"], out.reshape(-1).numpy()) >= min_db
+
+
+def test_config_and_checkpoint_drop_in(tmp_path, built):
+    import quickvc_official_amd as q
+    from quickvc_official_amd.synth import make_synthetic_state_dict
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps({"train": {"segment_size": 10240, "seed": 1234},
+                                    "data": dict(q.DEFAULT_DATA_CONFIG), "model": dict(q.MINI_MODEL_CONFIG)}))
+    hps = q.get_hparams_from_file(str(cfg_path))
+    assert hps.data.filter_length == 1280 and hps.train["segment_size"] == 10240 and "model" in hps
+    net = q.SynthesizerTrn(hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length, **hps.model)
+    assert net.samples_per_frame == 320
+    assert sum(p.numel() for p in net.parameters()) > 0
+    sd = make_synthetic_state_dict(net, 9)
+    ck = tmp_path / "G_100.pth"
+    torch.save({"model": {k: v for k, v in sd.items() if k != "enc_p.pre.bias"}, "iteration": 100,
+                "optimizer": None, "learning_rate": 2e-4, "extra_key_ignored": 1}, ck)
+    torch.save({"model": sd, "iteration": 20, "optimizer": None, "learning_rate": 1e-4}, tmp_path / "G_20.pth")
+    before = net.state_dict()["enc_p.pre.bias"].clone()
+    _, _, lr, it = q.load_checkpoint(str(ck), net, None)
+    assert (lr, it) == (2e-4, 100)
+    assert torch.equal(net.state_dict()["enc_p.pre.bias"], before)                 # missing key keeps own value
+    assert torch.equal(net.state_dict()["dec.conv_pre.weight_v"], sd["dec.conv_pre.weight_v"])
+    assert q.latest_checkpoint_path(str(tmp_path)).endswith("G_100.pth")
+    with pytest.raises(RuntimeError, match="Not-supported decoder flag"):
+        q.SynthesizerTrn(641, 32, **dict(q.MINI_MODEL_CONFIG, ms_istft_vits=False))
+    with pytest.raises(AssertionError):
+        q.SynthesizerTrn(641, 32, **dict(q.MINI_MODEL_CONFIG, resblock="2"))
+
+
+def test_sharding_is_a_partition():
+    from quickvc_official_amd.dist import shard_indices
+    lengths = [int(x) for x in np.random.RandomState(0).randint(50, 400, size=37)]
+    for world in (1, 2, 3, 8):
+        shards = [shard_indices(37, r, world, lengths) for r in range(world)]
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(37))
+        loads = [sum(lengths[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lengths)
+
+
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from quickvc_official_amd import dist as qd
+rank, _, world = qd.env_world()
+dist.init_process_group("gloo", rank=rank, world_size=world)
+blob = torch.arange(1000, dtype=torch.int64).to(torch.uint8) if rank == 0 else torch.zeros(1000, dtype=torch.uint8)
+qd.broadcast_blob(blob, src=0)
+ok = bool((blob == torch.arange(1000, dtype=torch.int64).to(torch.uint8)).all())
+mine = qd.shard_indices(10, rank, world)
+wall = qd.max_over_ranks(1.0 + rank, torch.device("cpu"))
+total = qd.sum_over_ranks(float(len(mine)), torch.device("cpu"))
+print(json.dumps({{"rank": rank, "ok": ok, "mine": mine, "wall": wall, "total": total}}))
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_2_broadcast_and_sharding_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=180)
+        assert p.returncode == 0, se
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert all(d["ok"] for d in outs)
+    assert outs[0]["mine"] == [0, 2, 4, 6, 8] and outs[1]["mine"] == [1, 3, 5, 7, 9]
+    assert all(d["wall"] == 2.0 and d["total"] == 10.0 for d in outs)
