@@ -224,7 +224,7 @@ class SynthesizerTrn(nn.Module):
                  upsample_rates: List[int], upsample_initial_channel: int, upsample_kernel_sizes: List[int],
                  gen_istft_n_fft: int, gen_istft_hop_size: int,
                  istft_vits: bool = False, ms_istft_vits: bool = False, mb_istft_vits: bool = False,
-                 subbands=False, gin_channels: int = 0, operand_dtype: str = "bf16", verbose: bool = False,
+                 subbands=False, gin_channels: int = 0, operand_dtype: str = "f16", verbose: bool = False,
                  **kwargs):
         super().__init__()
         if verbose:

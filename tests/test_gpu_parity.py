@@ -174,6 +174,7 @@ def test_infer_api_matches_reference_semantics(lib, dev):
     entry, _ = load_case("mini")
     spk = dict(np.load(os.path.join(helpers.GOLDEN, "mini_spk.npz")))
     model, sd, unit, g, noise = regenerate(entry)
+    assert model.model_config["operand_dtype"] == "f16"        # the default must be the one that meets 40 dB
     model.load_state_dict(sd)
     model = model.cuda().eval()
     mel = make_synthetic_mel(300, 80, seed=307)
