@@ -66,14 +66,14 @@ struct EmuBackend {
     std::vector<float> W((size_t)MP * nIt * kKStep, 0.f);   // [packed row][it][32]
     const uint16_t* src = static_cast<const uint16_t*>(a.w);
     for (int chunk = 0; chunk < d.nchunk; ++chunk)
-      for (int wave = 0; wave < kWaves; ++wave)
+      for (int wave = 0; wave < d.WM; ++wave)
         for (int it = 0; it < nIt; ++it)
           for (int mf = 0; mf < d.MF; ++mf)
             for (int lane = 0; lane < 64; ++lane)
               for (int j = 0; j < 8; ++j) {
-                const size_t frag = ((size_t)(chunk * kWaves + wave) * nIt + it) * d.MF + mf;
+                const size_t frag = ((size_t)(chunk * d.WM + wave) * nIt + it) * d.MF + mf;
                 const uint16_t h = src[(frag * 64 + lane) * 8 + j];
-                const int prow = ((chunk * kWaves + wave) * d.MF + mf) * 16 + (lane & 15);
+                const int prow = ((chunk * d.WM + wave) * d.MF + mf) * 16 + (lane & 15);
                 const int k = (lane >> 4) * 8 + j;
                 W[((size_t)prow * nIt + it) * kKStep + k] = dtype == QVC_F16 ? from_f16(h) : from_bf16(h);
               }
@@ -94,7 +94,7 @@ struct EmuBackend {
             if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)s * a.x_ts + a.x_c0 + c], a.slope_in), dtype);
           } else if (a.x_kind == XK_OP_FM) {
             ok = ti >= 0 && ti < a.T_in;
-            if (ok) { uint16_t h = static_cast<const uint16_t*>(a.x)[(size_t)b * a.x_bs + (size_t)ti * a.x_ts + a.x_c0 + c]; v = dtype == QVC_F16 ? from_f16(h) : from_bf16(h); }
+            if (ok) { uint16_t h = static_cast<const uint16_t*>(a.x)[(size_t)b * a.x_bs + (size_t)ti * a.x_ts + a.x_c0 + c]; v = dtype == QVC_F16 ? from_f16(h) : from_bf16(h); if (a.slope_in != 1.f) v = round_op(lrelu(v, a.slope_in), dtype); }
           } else {
             ok = ti >= 0 && ti < a.T_in;
             if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)c * a.x_ts + ti], a.slope_in), dtype);
@@ -103,10 +103,10 @@ struct EmuBackend {
         }
       }
       for (int chunk = 0; chunk < d.nchunk; ++chunk)
-        for (int wave = 0; wave < kWaves; ++wave)
+        for (int wave = 0; wave < d.WM; ++wave)
           for (int mf = 0; mf < d.MF; ++mf)
             for (int i = 0; i < 16; ++i) {
-              const int prow = ((chunk * kWaves + wave) * d.MF + mf) * 16 + i;
+              const int prow = ((chunk * d.WM + wave) * d.MF + mf) * 16 + i;
               for (int q = 0; q < a.Nq; ++q) {
                 double acc = 0.0;
                 for (int it = 0; it < nIt; ++it) {
@@ -131,13 +131,14 @@ struct EmuBackend {
       static_cast<uint16_t*>(base)[off] = dtype == QVC_F16 ? to_f16(std::fmin(std::fmax(v, -65504.f), 65504.f)) : to_bf16(v);
     };
     if (epi == EPI_GAU) {
-      const int H = a.gau_H;
+      const int H = a.gau_H, hf = d.MF / 2;
       for (int chunk = 0; chunk < d.nchunk; ++chunk)
-        for (int wave = 0; wave < kWaves; ++wave)
+        for (int wave = 0; wave < d.WM; ++wave)
+         for (int f = 0; f < hf; ++f)
           for (int i = 0; i < 16; ++i) {
-            const int ch = chunk * 64 + wave * 16 + i;
+            const int ch = ((chunk * d.WM + wave) * hf + f) * 16 + i;
             if (ch >= H) continue;
-            const int pt = ((chunk * kWaves + wave) * 2 + 0) * 16 + i, ps = ((chunk * kWaves + wave) * 2 + 1) * 16 + i;
+            const int pt = ((chunk * d.WM + wave) * d.MF + f) * 16 + i, ps = ((chunk * d.WM + wave) * d.MF + hf + f) * 16 + i;
             const float* bb = a.bbias + (size_t)b * a.bbias_bs;
             for (int q = 0; q < a.Nq; ++q) {
               const float t = acc_[idx(pt, q, a.Nq)] + bb[ch], s = acc_[idx(ps, q, a.Nq)] + bb[H + ch];
@@ -157,6 +158,7 @@ struct EmuBackend {
         float val = acc_[idx(v, q, a.Nq)] + bias;
         if (a.y32b && v >= a.split) { a.y32b[(size_t)b * a.y32_bs + (size_t)o * a.y32_ts + (v - a.split)] += val; continue; }
         if (a.res) val = a.res[(size_t)b * a.res_bs + (size_t)o * a.res_ts + a.res_c0 + co] + a.res_sign * val;
+        if (a.res16) { const uint16_t h = static_cast<const uint16_t*>(a.res16)[(size_t)b * a.res_bs + (size_t)o * a.res_ts + co]; val = (dtype == QVC_F16 ? from_f16(h) : from_bf16(h)) + a.res_sign * val; }
         if (a.y32) {
           float* p = a.y32 + (size_t)b * a.y32_bs + (size_t)o * a.y32_ts + a.y32_c0 + co;
           *p = (a.y_accum ? *p : 0.f) + val * a.y_scale;
@@ -166,6 +168,24 @@ struct EmuBackend {
     }
   }
 
+  // fused pair = the two convs back to back with the intermediate rounded to the operand type
+  int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& p, int B, int dtype) {
+    std::vector<uint16_t> xt((size_t)B * p.bs);
+    auto fill = [](ConvArgs& a, const ConvDesc& d) {
+      a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left; a.KS = d.KS(); a.nIt = d.nIt();
+      a.nchunk = d.nchunk; a.M = d.M; a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout; };
+    ConvArgs a1; fill(a1, d1);
+    a1.w = p.w1; a1.bias = p.b1; a1.x = p.x; a1.x_kind = XK_OP_FM; a1.x_bs = p.bs; a1.x_ts = p.C; a1.T_in = p.T; a1.slope_in = p.slope;
+    a1.Nq = p.T; a1.T_out = p.T; a1.y16 = xt.data(); a1.y16_bs = p.bs; a1.y16_ts = p.C; a1.slope_out = p.slope;
+    conv(d1, a1, B, EPI_STD, dtype);
+    ConvArgs a2; fill(a2, d2);
+    a2.w = p.w2; a2.bias = p.b2; a2.x = xt.data(); a2.x_kind = XK_OP_FM; a2.x_bs = p.bs; a2.x_ts = p.C; a2.T_in = p.T;
+    a2.Nq = p.T; a2.T_out = p.T; a2.res16 = p.x; a2.res_bs = p.bs; a2.res_ts = p.C;
+    if (p.m32) { a2.y32 = p.m32; a2.y32_bs = p.bs; a2.y32_ts = p.C; a2.y_scale = p.scale; a2.y_accum = p.accum; }
+    else { a2.y16 = p.y; a2.y16_bs = p.bs; a2.y16_ts = p.C; a2.slope_out = 1.f; }
+    conv(d2, a2, B, EPI_STD, dtype);
+    return QVC_OK;
+  }
   int gemv(const GemvArgs& a) {
     for (int b = 0; b < a.batch; ++b)
       for (int r = 0; r < a.rows; ++r) {
@@ -273,7 +293,7 @@ int64_t qvc_emu_tap_offset(const qvc_config* cfg, int32_t batch, int32_t frames,
     case 1: return W.post;
     case 2: return W.m[0];
     case 3: return W.m.size() > 1 ? W.m[1] : -1;
-    case 4: return W.u[0];
+    case 4: return W.u[0];   // operand type since the fused-pair path
     case 5: return W.stats;
     default: return -1;
   }

@@ -20,6 +20,7 @@ using namespace qvc;
 struct HipBackend {
   hipStream_t stream;
   int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) { return launch_conv(d, a, batch, epi, dtype, stream); }
+  int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& a, int batch, int dtype) { return launch_pair(d1, d2, a, batch, dtype, stream); }
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
@@ -44,7 +45,7 @@ struct TimedBackend {
     int st = launch_conv(d, a, batch, epi, dtype, stream, &nf);
     mark();
     char name[48];
-    std::snprintf(name, sizeof(name), "conv<%s,MF%d,NF%d,%s>", dtype == QVC_F16 ? "f16" : "bf16", d.MF, nf, epi == EPI_GAU ? "gau" : "std");
+    std::snprintf(name, sizeof(name), "conv<%s,MF%d,NF%d,WM%d,%s>", dtype == QVC_F16 ? "f16" : "bf16", d.MF, nf, d.WM, epi == EPI_GAU ? "gau" : "std");
     // algorithmic work: a transposed conv does k MACs per (input frame, ci, co), a conv taps MACs per output
     const double macs = d.up_s > 1 ? (double)batch * a.T_in * d.Cin * d.Cout * (double)d.ksize
                                    : (double)batch * a.Nq * (double)d.M * d.taps * d.Cin;
@@ -56,9 +57,21 @@ struct TimedBackend {
       if (a.y32) out_b += outs * 4 * (a.y_accum ? 2 : 1);
       if (a.y16) out_b += outs * 2;
       if (a.res) out_b += outs * 4;
+      if (a.res16) out_b += outs * 2;
       if (a.y32b) out_b += (double)batch * a.Nq * (d.M - a.split) * 8;
     }
     note(name, 2.0 * macs, in_b + out_b + (double)d.w_bytes());
+    return st;
+  }
+  int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& a, int batch, int dtype) {
+    if (ev.empty()) mark();
+    int nf = 0;
+    int st = launch_pair(d1, d2, a, batch, dtype, stream, &nf);
+    mark();
+    char name[48];
+    std::snprintf(name, sizeof(name), "rbpair<%s,MF%d,NF%d,WM%d>", dtype == QVC_F16 ? "f16" : "bf16", d1.MF, nf, d1.WM);
+    const double outs = (double)batch * a.T * a.C;
+    note(name, 2.0 * 2.0 * outs * a.C * a.k, outs * 2 * 2 + outs * (a.m32 ? (a.accum ? 8 : 4) : 2) + (double)d1.w_bytes() + (double)d2.w_bytes());
     return st;
   }
   int gemv(const GemvArgs& a) { if (ev.empty()) mark(); int st = launch_gemv(a, stream); mark();

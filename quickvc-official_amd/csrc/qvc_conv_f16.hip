@@ -1,4 +1,5 @@
 // fp16-operand instantiation of the conv kernel (own translation unit so the two operand
 // types compile in parallel).
 #include "qvc_conv_impl.h"
-namespace qvc { template int launch_conv_typed<_Float16>(const ConvDesc&, const ConvArgs&, int, int, void*, int*); }
+namespace qvc { template int launch_conv_typed<_Float16>(const ConvDesc&, const ConvArgs&, int, int, void*, int*);
+template int launch_pair_typed<_Float16>(const ConvDesc&, const PairArgs&, int, void*, int*); }

@@ -18,6 +18,7 @@
 //     MRF averaging, leaky-ReLU + down-conversion, the WaveNet gate and the res/skip split.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "qvc_kernels.h"
 
 namespace qvc {
@@ -53,127 +54,210 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f / (__expf(2.f * x) + 1.f);
 }
 
-// 16-byte-chunk swizzle of a tile row (see tools: bank simulation in DESIGN.md).
-__device__ __forceinline__ int swz(int row, int mode) {
-  return mode == 0 ? (row & 15) : (mode == 1 ? (row & 7) : ((row >> 1) & 3));
+// 16-byte-chunk swizzle of a tile row: chunk ^= (row >> sh) & mask, branch-free.  The three modes
+// (mask 15 / 7 for rows of 16k / 8k chunks, (row>>1)&3 otherwise) come from a bank-conflict
+// simulation of the ds_read_b128 lane groups; all are invariant under row += 16.
+struct Swz { int sh, mask; };
+__device__ __forceinline__ Swz swz_mode(int cpr) {
+  return (cpr & 15) == 0 ? Swz{0, 15} : ((cpr & 7) == 0 ? Swz{0, 7} : Swz{1, 3});
+}
+__device__ __forceinline__ int swz(int row, Swz m) { return (row >> m.sh) & m.mask; }
+
+// leaky ReLU on 8 packed operand values (slope <= 1): max(x, slope*x), in operand arithmetic
+template <typename T>
+__device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, float slope) {
+  typename Op<T>::frag r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float f = (float)v[i];
+    r[i] = (T)(f > 0.f ? f : f * slope);     // exact in fp32, one rounding back to T
+  }
+  return r;
 }
 
-template <typename T, int MF, int NF, int EPI>
+constexpr int kPF = 2;   // A fragments are prefetched this many k-steps ahead (register ring of kPF+1)
+
+// The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
+// wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
+template <typename T, int MF, int NF>
+__device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
+                                          const char* tile, int rowbytes, Swz sm, int colrow, int lq) {
+  using O = Op<T>;
+  using frag = typename O::frag;
+  constexpr int RING = kPF + 1;
+  frag ar[RING][MF];
+#pragma unroll
+  for (int u = 0; u < kPF; ++u)
+    if (u < nIt) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)u * MF + m) * 64];
+    }
+  const int nstride = 16 * rowbytes;
+  int tap = 0, ks = 0;
+  for (int it0 = 0; it0 < nIt; it0 += RING) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      const int it = it0 + u;
+      if (it < nIt) {                                           // wave-uniform
+        if (it + kPF < nIt) {
+#pragma unroll
+          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)(it + kPF) * MF + m) * 64];
+        }
+        const int row0 = tap * dil + colrow;
+        const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
+        frag bf[NF];
+#pragma unroll
+        for (int n = 0; n < NF; ++n) bf[n] = *reinterpret_cast<const frag*>(bp + n * nstride);
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int m = 0; m < MF; ++m) acc[m][n] = O::mfma(ar[u][m], bf[n], acc[m][n]);
+        if (++ks == KS) { ks = 0; ++tap; }
+      }
+    }
+  }
+}
+
+// WM waves along M, WN = 4/WM along the frames; block tile = [WM*MF*16 rows] x [WN*NF*16 frames].
+template <typename T, int MF, int NF, int WM, int EPI>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WN = kWaves / WM;
+  constexpr int NT = WN * NF * 16;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
   const int b = blockIdx.y, chunk = blockIdx.z;
-  constexpr int NT = NF * 16;
   const int q0 = blockIdx.x * NT;
   const int R = NT + (a.taps - 1) * a.dil;
   const int rowbytes = a.CinP * 2;
   const int cpr = a.CinP >> 3;                                  // 16-byte chunks per row
-  const int smode = (cpr & 15) == 0 ? 0 : ((cpr & 7) == 0 ? 1 : 2);
+  const Swz sm = swz_mode(cpr);
   const int t_base = q0 - a.left;                               // input frame of tile row 0
 
   // ------------------------------------------------------------------ stage the activation tile
+  // Loads are issued in batches per thread before anything is converted or stored, so that one
+  // workgroup alone keeps tens of KiB of reads in flight.
+  constexpr int kU = 4;
   if (a.x_kind == XK_F32_FM) {
     const float* xb = static_cast<const float*>(a.x) + (size_t)b * a.x_bs + a.x_c0;
     const float slope = a.slope_in;
-    for (int idx = tid; idx < R * cpr; idx += 256) {
-      const int r = idx / cpr, c8 = idx - r * cpr;
-      const int ti = t_base + r;
-      bool ok; int src;
-      if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; src = ti == 0 ? 1 : ti - 1; }
-      else { ok = ti >= 0 && ti < a.T_in; src = ti; }
-      ok = ok && (c8 * 8 < a.Cin);
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (ok) {
-        const float4* p = reinterpret_cast<const float4*>(xb + (size_t)src * a.x_ts + c8 * 8);
-        v0 = p[0]; v1 = p[1];
+    const int total = R * cpr;
+    for (int base = tid; base < total; base += 256 * kU) {
+      float4 v0[kU], v1[kU];
+      int dst[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * 256;
+        const int r = idx / cpr, c8 = idx - r * cpr;
+        const int ti = t_base + r;
+        bool ok; int src;
+        if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; src = ti == 0 ? 1 : ti - 1; }
+        else { ok = ti >= 0 && ti < a.T_in; src = ti; }
+        ok = ok && idx < total && (c8 * 8 < a.Cin);
+        v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
+        if (ok) {
+          const float4* p = reinterpret_cast<const float4*>(xb + (size_t)src * a.x_ts + c8 * 8);
+          v0[u] = p[0]; v1[u] = p[1];
+        }
+        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
       }
-      frag h;
-      h[0] = O::cvt(lrelu(v0.x, slope)); h[1] = O::cvt(lrelu(v0.y, slope));
-      h[2] = O::cvt(lrelu(v0.z, slope)); h[3] = O::cvt(lrelu(v0.w, slope));
-      h[4] = O::cvt(lrelu(v1.x, slope)); h[5] = O::cvt(lrelu(v1.y, slope));
-      h[6] = O::cvt(lrelu(v1.z, slope)); h[7] = O::cvt(lrelu(v1.w, slope));
-      *reinterpret_cast<frag*>(smem + r * rowbytes + ((c8 ^ swz(r, smode)) << 4)) = h;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (dst[u] < 0) continue;
+        frag h;
+        h[0] = O::cvt(lrelu(v0[u].x, slope)); h[1] = O::cvt(lrelu(v0[u].y, slope));
+        h[2] = O::cvt(lrelu(v0[u].z, slope)); h[3] = O::cvt(lrelu(v0[u].w, slope));
+        h[4] = O::cvt(lrelu(v1[u].x, slope)); h[5] = O::cvt(lrelu(v1[u].y, slope));
+        h[6] = O::cvt(lrelu(v1[u].z, slope)); h[7] = O::cvt(lrelu(v1[u].w, slope));
+        *reinterpret_cast<frag*>(smem + dst[u]) = h;
+      }
     }
   } else if (a.x_kind == XK_OP_FM) {
     const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.x_bs + a.x_c0;
-    for (int idx = tid; idx < R * cpr; idx += 256) {
-      const int r = idx / cpr, c8 = idx - r * cpr;
-      const int ti = t_base + r;
-      const bool ok = ti >= 0 && ti < a.T_in && (c8 * 8 < a.Cin);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.x_ts + c8 * 8);
-      *reinterpret_cast<uint4*>(smem + r * rowbytes + ((c8 ^ swz(r, smode)) << 4)) = v;
+    const int total = R * cpr;
+    for (int base = tid; base < total; base += 256 * kU * 2) {
+      uint4 v[kU * 2];
+      int dst[kU * 2];
+#pragma unroll
+      for (int u = 0; u < kU * 2; ++u) {
+        const int idx = base + u * 256;
+        const int r = idx / cpr, c8 = idx - r * cpr;
+        const int ti = t_base + r;
+        const bool ok = idx < total && ti >= 0 && ti < a.T_in && (c8 * 8 < a.Cin);
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.x_ts + c8 * 8);
+        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kU * 2; ++u)
+        if (dst[u] >= 0) {
+          if (a.slope_in != 1.f) {
+            frag h; __builtin_memcpy(&h, &v[u], 16);
+            h = lrelu8<T>(h, a.slope_in);
+            *reinterpret_cast<frag*>(smem + dst[u]) = h;
+          } else {
+            *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
+          }
+        }
     }
   } else {  // XK_F32_CM: (B, C, T) -- consecutive threads walk along T (coalesced), transposed into the tile
     const float* xb = static_cast<const float*>(a.x) + (size_t)b * a.x_bs;
     const float slope = a.slope_in;
-    for (int idx = tid; idx < R * a.CinP; idx += 256) {
-      const int c = idx / R, r = idx - c * R;
-      const int ti = t_base + r;
-      float v = 0.f;
-      if (c < a.Cin && ti >= 0 && ti < a.T_in) v = lrelu(xb[(size_t)c * a.x_ts + ti], slope);
-      *reinterpret_cast<T*>(smem + r * rowbytes + (((c >> 3) ^ swz(r, smode)) << 4) + (c & 7) * 2) = O::cvt(v);
+    const int total = R * a.CinP;
+    for (int base = tid; base < total; base += 256 * kU * 2) {
+      float v[kU * 2];
+      int dst[kU * 2];
+#pragma unroll
+      for (int u = 0; u < kU * 2; ++u) {
+        const int idx = base + u * 256;
+        const int c = idx / R, r = idx - c * R;
+        const int ti = t_base + r;
+        v[u] = 0.f;
+        if (idx < total && c < a.Cin && ti >= 0 && ti < a.T_in) v[u] = xb[(size_t)c * a.x_ts + ti];
+        dst[u] = idx < total ? r * rowbytes + (((c >> 3) ^ swz(r, sm)) << 4) + (c & 7) * 2 : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kU * 2; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<T*>(smem + dst[u]) = O::cvt(lrelu(v[u], slope));
     }
   }
   __syncthreads();
 
-  // ------------------------------------------------------------------ K loop: A from global, B from LDS
+  // ------------------------------------------------------------------ K loop: A from global (ring), B from LDS
   f32x4 acc[MF][NF];
 #pragma unroll
   for (int m = 0; m < MF; ++m)
 #pragma unroll
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const frag* ap = static_cast<const frag*>(a.w) + ((size_t)(chunk * kWaves + wave) * a.nIt * MF) * 64 + lane;
-  frag a_nxt[MF];
-#pragma unroll
-  for (int m = 0; m < MF; ++m) a_nxt[m] = ap[m * 64];
-
+  const frag* ap = static_cast<const frag*>(a.w) + ((size_t)(chunk * WM + wm) * a.nIt * MF) * 64 + lane;
   const int lrow = lane & 15, lq = lane >> 4;
-  int tap = 0, ks = 0;
-  for (int it = 0; it < a.nIt; ++it) {
-    frag a_cur[MF];
-#pragma unroll
-    for (int m = 0; m < MF; ++m) a_cur[m] = a_nxt[m];
-    if (it + 1 < a.nIt) {
-#pragma unroll
-      for (int m = 0; m < MF; ++m) a_nxt[m] = ap[((size_t)(it + 1) * MF + m) * 64];
-    }
-    const int row0 = tap * a.dil + lrow;
-    const int ch = ks * 4 + lq;
-    frag bf[NF];
-#pragma unroll
-    for (int n = 0; n < NF; ++n) {
-      const int row = row0 + n * 16;
-      bf[n] = *reinterpret_cast<const frag*>(smem + row * rowbytes + ((ch ^ swz(row, smode)) << 4));
-    }
-#pragma unroll
-    for (int m = 0; m < MF; ++m)
-#pragma unroll
-      for (int n = 0; n < NF; ++n) acc[m][n] = O::mfma(a_cur[m], bf[n], acc[m][n]);
-    if (++ks == a.KS) { ks = 0; ++tap; }
-  }
+  gemm_loop<T, MF, NF>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq);
 
   // ------------------------------------------------------------------ epilogue
+  const int qw = q0 + wn * (NF * 16);                           // first frame of this wave's columns
   if constexpr (EPI == EPI_GAU) {
-    // rows: m = 0 tanh half, m = 1 sigmoid half of channels chunk*64 + wave*16 + ...
-    static_assert(EPI != EPI_GAU || MF == 2, "GAU epilogue pairs two fragments per wave");
+    // fragments [0, MF/2) = tanh rows, [MF/2, MF) = sigmoid rows of the same channels
+    static_assert(EPI != EPI_GAU || MF % 2 == 0, "GAU epilogue pairs fragments");
+    constexpr int HF = MF / 2;
     const int H = a.gau_H;
-    const int ch0 = chunk * 64 + wave * 16 + lq * 4;
-    if (ch0 < H) {
-      const float* bb = a.bbias + (size_t)b * a.bbias_bs;
+    const float* bb = a.bbias + (size_t)b * a.bbias_bs;
+#pragma unroll
+    for (int f = 0; f < HF; ++f) {
+      const int ch0 = ((chunk * WM + wm) * HF + f) * 16 + lq * 4;
+      if (ch0 >= H) continue;
       const float4 bt = *reinterpret_cast<const float4*>(bb + ch0);
       const float4 bs = *reinterpret_cast<const float4*>(bb + H + ch0);
       T* yb = static_cast<T*>(a.y16) + (size_t)b * a.y16_bs + ch0;
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
-        const int q = q0 + n * 16 + lrow;
+        const int q = qw + n * 16 + lrow;
         if (q < a.Nq) {
-          const f32x4 t = acc[0][n], s = acc[MF - 1][n];
+          const f32x4 t = acc[f][n], s = acc[HF + f][n];
           typename O::quad o;
           o[0] = O::cvt(fast_tanh(t[0] + bt.x) * fast_sigmoid(s[0] + bs.x));
           o[1] = O::cvt(fast_tanh(t[1] + bt.y) * fast_sigmoid(s[1] + bs.y));
@@ -186,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   } else {
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-      const int v = ((chunk * kWaves + wave) * MF + m) * 16 + lq * 4;
+      const int v = ((chunk * WM + wm) * MF + m) * 16 + lq * 4;
       if (v >= a.M) continue;
       int ph = 0, co = v;
       if (a.up_s > 1) { ph = v / a.Cout; co = v - ph * a.Cout; }
@@ -198,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
-        const int q = q0 + n * 16 + lrow;
+        const int q = qw + n * 16 + lrow;
         const int o = q * a.up_s + ph - a.up_p;
         if (q >= a.Nq || o < 0 || o >= a.T_out) continue;
         float4 val = make_float4(acc[m][n][0] + bias.x, acc[m][n][1] + bias.y, acc[m][n][2] + bias.z, acc[m][n][3] + bias.w);
@@ -213,6 +297,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           const float4 rr = *reinterpret_cast<const float4*>(a.res + (size_t)b * a.res_bs + (size_t)o * a.res_ts + a.res_c0 + co);
           val.x = rr.x + a.res_sign * val.x; val.y = rr.y + a.res_sign * val.y;
           val.z = rr.z + a.res_sign * val.z; val.w = rr.w + a.res_sign * val.w;
+        }
+        if (a.res16) {
+          const typename O::quad rr = *reinterpret_cast<const typename O::quad*>(
+              static_cast<const T*>(a.res16) + (size_t)b * a.res_bs + (size_t)o * a.res_ts + co);
+          val.x = (float)rr[0] + a.res_sign * val.x; val.y = (float)rr[1] + a.res_sign * val.y;
+          val.z = (float)rr[2] + a.res_sign * val.z; val.w = (float)rr[3] + a.res_sign * val.w;
         }
         if (a.y32) {
           float* p = a.y32 + (size_t)b * a.y32_bs + (size_t)o * a.y32_ts + a.y32_c0 + co;
@@ -234,73 +324,279 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ fused ResBlock1 pair
+// y = x + conv2(lrelu(conv1(lrelu(x))))  (modules.py:148-153) in ONE kernel.  The activated input tile
+// is staged once; GEMM1 produces the intermediate for NT + 2*h2 frames (its own 'same' halo), which
+// after bias + leaky-ReLU OVERWRITES the input tile in LDS (the input is dead by then), GEMM2 runs
+// from there, and the epilogue adds the raw residual.  Compared with two launches this removes the
+// intermediate's HBM round trip and one staging pass; the price is NF+1 instead of NF column
+// fragments in GEMM1.  The residual stream is carried in the operand type (costs 0.35 dB).
+template <typename T, int MF, int NF, int WM>
+__global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
+  using O = Op<T>;
+  using frag = typename O::frag;
+  using quad = typename O::quad;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WN = kWaves / WM;
+  constexpr int NF1 = NF + 1;
+  constexpr int NT = WN * NF * 16;       // output frames per block
+  constexpr int N1P = WN * NF1 * 16;     // intermediate frames computed per block (>= NT + 2*h2)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * NT;
+  const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
+  const int Rx = N1P + 2 * h1;           // staged rows; row 0 <-> frame q0 - h2 - h1
+  const int rowbytes = a.CP * 2;
+  const int cpr = a.CP >> 3;
+  const Swz sm = swz_mode(cpr);
+  const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
+
+  {   // ---- stage lrelu(x)
+    const int t_base = q0 - h2 - h1;
+    const int total = Rx * cpr;
+    constexpr int kU = 8;
+    for (int base = tid; base < total; base += 256 * kU) {
+      uint4 v[kU];
+      int dst[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * 256;
+        const int r = idx / cpr, c8 = idx - r * cpr;
+        const int ti = t_base + r;
+        const bool ok = idx < total && ti >= 0 && ti < a.T && (c8 * 8 < a.C);
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
+        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (dst[u] >= 0) {
+          frag h; __builtin_memcpy(&h, &v[u], 16);
+          *reinterpret_cast<frag*>(smem + dst[u]) = lrelu8<T>(h, a.slope);
+        }
+    }
+  }
+  __syncthreads();
+
+  {   // ---- GEMM1 over N1P frames, then bias + lrelu -> intermediate tile (in place of the input tile)
+    f32x4 acc[MF][NF1];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF1; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const frag* ap = static_cast<const frag*>(a.w1) + ((size_t)wm * a.nIt * MF) * 64 + lane;
+    gemm_loop<T, MF, NF1>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF1 * 16) + lrow, lq);
+    __syncthreads();                     // every wave is done reading the input tile
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int v = (wm * MF + m) * 16 + lq * 4;
+      if (v >= a.CP) continue;
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < a.C) bias = *reinterpret_cast<const float4*>(a.b1 + v);
+#pragma unroll
+      for (int n = 0; n < NF1; ++n) {
+        const int j = wn * (NF1 * 16) + n * 16 + lrow;          // intermediate row <-> frame q0 - h2 + j
+        const int f = q0 - h2 + j;
+        quad h;
+        if (f >= 0 && f < a.T && v < a.C) {                      // conv2 zero-pads outside [0, T)
+          h[0] = O::cvt(lrelu(acc[m][n][0] + bias.x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias.y, a.slope));
+          h[2] = O::cvt(lrelu(acc[m][n][2] + bias.z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias.w, a.slope));
+        } else {
+          h[0] = h[1] = h[2] = h[3] = (T)0.f;
+        }
+        *reinterpret_cast<quad*>(smem + j * rowbytes + (((v >> 3) ^ swz(j, sm)) << 4) + (v & 7) * 2) = h;
+      }
+    }
+  }
+  __syncthreads();
+
+  {   // ---- GEMM2 over NT frames (dilation 1) + bias + residual
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
+    gemm_loop<T, MF, NF>(acc, ap, a.nIt, a.KS, 1, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int v = (wm * MF + m) * 16 + lq * 4;
+      if (v >= a.C) continue;
+      const float4 bias = *reinterpret_cast<const float4*>(a.b2 + v);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = q0 + wn * (NF * 16) + n * 16 + lrow;
+        if (q >= a.T) continue;
+        const size_t off = (size_t)b * a.bs + (size_t)q * a.C + v;
+        const quad rr = *reinterpret_cast<const quad*>(static_cast<const T*>(a.x) + off);
+        float4 val = make_float4(acc[m][n][0] + bias.x + (float)rr[0], acc[m][n][1] + bias.y + (float)rr[1],
+                                 acc[m][n][2] + bias.z + (float)rr[2], acc[m][n][3] + bias.w + (float)rr[3]);
+        if (a.m32) {
+          float* p = a.m32 + off;
+          float4 out = make_float4(val.x * a.scale, val.y * a.scale, val.z * a.scale, val.w * a.scale);
+          if (a.accum) {
+            const float4 old = *reinterpret_cast<const float4*>(p);
+            out.x += old.x; out.y += old.y; out.z += old.z; out.w += old.w;
+          }
+          *reinterpret_cast<float4*>(p) = out;
+        } else {
+          quad h;
+          h[0] = O::cvt(val.x); h[1] = O::cvt(val.y); h[2] = O::cvt(val.z); h[3] = O::cvt(val.w);
+          *reinterpret_cast<quad*>(static_cast<T*>(a.y) + off) = h;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ launch-side tile selection
 struct TileChoice { int NF; int blocks; size_t lds; };
 
-inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, int epi, const int* nf_list, int n_nf) {
+inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* nf_list, int n_nf) {
   const int halo = (d.taps - 1) * d.dil;
   const int rowbytes = d.CinP * 2;
+  const int WN = kWaves / d.WM;
   TileChoice best{0, 0, 0};
   double best_cost = 1e300;
   for (int i = 0; i < n_nf; ++i) {
     const int NF = nf_list[i];
-    if (d.MF * NF * 4 > 160 || (NF == 10 && d.MF > 2)) continue;   // accumulator registers / built variants
-    const size_t lds = (size_t)(NF * 16 + halo) * rowbytes;
+    if (d.MF * NF * 4 > 160) continue;                          // accumulator registers
+    const int NT = WN * NF * 16;
+    const size_t lds = (size_t)(NT + halo) * rowbytes;
     if (lds > 160 * 1024) continue;
-    const int tiles = ceil_div(Nq, NF * 16);
+    const int tiles = ceil_div(Nq, NT);
     const long blocks = (long)tiles * batch * d.nchunk;
     const long per_cu = (blocks + 255) / 256;
     // work per block ~ frames computed + a fixed overhead (staging, launch, epilogue), in frame units
-    const double cost = (double)per_cu * (NF * 16 + 0.35 * halo + 24.0);
+    const double cost = (double)per_cu * (NT + 0.35 * halo + 24.0);
     if (cost < best_cost) { best_cost = cost; best = TileChoice{NF, (int)blocks, lds}; }
   }
-  (void)epi;
   return best;
 }
 
-template <typename T, int MF, int NF, int EPI>
-inline int launch_one(const ConvArgs& a, int batch, int Nq, size_t lds, hipStream_t stream) {
-  auto kern = conv_mfma_kernel<T, MF, NF, EPI>;
+template <typename T, int MF, int NF, int WM, int EPI>
+inline int launch_one(const ConvArgs& a, int batch, size_t lds, hipStream_t stream) {
+  auto kern = conv_mfma_kernel<T, MF, NF, WM, EPI>;
   static bool attr_done = false;                             // one-time opt-in for > 64 KiB dynamic LDS
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return QVC_ERR_LAUNCH;
     attr_done = true;
   }
-  dim3 grid((unsigned)ceil_div(Nq, NF * 16), (unsigned)batch, (unsigned)a.nchunk);
+  constexpr int NT = (kWaves / WM) * NF * 16;
+  dim3 grid((unsigned)ceil_div(a.Nq, NT), (unsigned)batch, (unsigned)a.nchunk);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
-template <typename T, int MF, int EPI>
+template <typename T, int MF, int WM, int EPI>
 inline int launch_nf(const ConvDesc& d, const ConvArgs& a, int batch, hipStream_t stream, int* nf_out) {
   static const int nfs[] = {2, 4, 5, 8, 10};
-  const TileChoice tc = choose_tile(d, a.Nq, batch, EPI, nfs, 5);
+  const TileChoice tc = choose_tile(d, a.Nq, batch, nfs, 5);
   if (nf_out) *nf_out = tc.NF;
   switch (tc.NF) {
-    case 2: return launch_one<T, MF, 2, EPI>(a, batch, a.Nq, tc.lds, stream);
-    case 4: return launch_one<T, MF, 4, EPI>(a, batch, a.Nq, tc.lds, stream);
-    case 5: return launch_one<T, MF, 5, EPI>(a, batch, a.Nq, tc.lds, stream);
-    case 8: return launch_one<T, MF, 8, EPI>(a, batch, a.Nq, tc.lds, stream);
-    case 10:
-      if constexpr (MF <= 2) return launch_one<T, MF, 10, EPI>(a, batch, a.Nq, tc.lds, stream);
-      return QVC_ERR_BAD_CONFIG;
-    default: return QVC_ERR_BAD_CONFIG;                      // tile does not fit LDS
+    case 2: return launch_one<T, MF, 2, WM, EPI>(a, batch, tc.lds, stream);
+    case 4: return launch_one<T, MF, 4, WM, EPI>(a, batch, tc.lds, stream);
+    case 5: if constexpr (MF * 5 * 4 <= 160) return launch_one<T, MF, 5, WM, EPI>(a, batch, tc.lds, stream); break;
+    case 8: if constexpr (MF * 8 * 4 <= 160) return launch_one<T, MF, 8, WM, EPI>(a, batch, tc.lds, stream); break;
+    case 10: if constexpr (MF * 10 * 4 <= 160) return launch_one<T, MF, 10, WM, EPI>(a, batch, tc.lds, stream); break;
+    default: break;
   }
+  return QVC_ERR_BAD_CONFIG;                                 // no tile fits LDS / registers
 }
 
 template <typename T>
 int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream_v, int* nf_out) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (epi == EPI_GAU) {
-    if (d.MF != 2) return QVC_ERR_BAD_CONFIG;
-    return launch_nf<T, 2, EPI_GAU>(d, a, batch, stream, nf_out);
+    if (d.WM != 4) return QVC_ERR_BAD_CONFIG;
+    switch (d.MF) {
+      case 2: return launch_nf<T, 2, 4, EPI_GAU>(d, a, batch, stream, nf_out);
+      case 4: return launch_nf<T, 4, 4, EPI_GAU>(d, a, batch, stream, nf_out);
+      case 6: return launch_nf<T, 6, 4, EPI_GAU>(d, a, batch, stream, nf_out);
+      default: return QVC_ERR_BAD_CONFIG;
+    }
   }
-  switch (d.MF) {
-    case 1: return launch_nf<T, 1, EPI_STD>(d, a, batch, stream, nf_out);
-    case 2: return launch_nf<T, 2, EPI_STD>(d, a, batch, stream, nf_out);
-    case 3: return launch_nf<T, 3, EPI_STD>(d, a, batch, stream, nf_out);
-    case 4: return launch_nf<T, 4, EPI_STD>(d, a, batch, stream, nf_out);
+  switch (d.WM * 10 + d.MF) {
+    case 41: return launch_nf<T, 1, 4, EPI_STD>(d, a, batch, stream, nf_out);
+    case 42: return launch_nf<T, 2, 4, EPI_STD>(d, a, batch, stream, nf_out);
+    case 43: return launch_nf<T, 3, 4, EPI_STD>(d, a, batch, stream, nf_out);
+    case 44: return launch_nf<T, 4, 4, EPI_STD>(d, a, batch, stream, nf_out);
+    case 23: return launch_nf<T, 3, 2, EPI_STD>(d, a, batch, stream, nf_out);
+    case 24: return launch_nf<T, 4, 2, EPI_STD>(d, a, batch, stream, nf_out);
+    case 14: return launch_nf<T, 4, 1, EPI_STD>(d, a, batch, stream, nf_out);
+    default: return QVC_ERR_BAD_CONFIG;
+  }
+}
+
+// ---- fused pair: tile choice + dispatch
+inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
+  static const int nfs[] = {2, 4, 5, 8};
+  const int WN = kWaves / d.WM;
+  const int halo1 = (d.taps - 1) * d.dil, rowbytes = d.CinP * 2;
+  TileChoice best{0, 0, 0};
+  double best_cost = 1e300;
+  for (int NF : nfs) {
+    if (d.MF * (NF + 1) * 4 > 160) continue;
+    const size_t lds = (size_t)(WN * (NF + 1) * 16 + halo1) * rowbytes;
+    if (lds > 160 * 1024) continue;
+    const int NT = WN * NF * 16;
+    const long blocks = (long)ceil_div(T, NT) * batch;
+    const int bpc = (int)std::min<size_t>(2, (160 * 1024) / lds);           // blocks that can share a CU
+    const long rounds = (blocks + 256L * bpc - 1) / (256L * bpc);
+    // per-block work in frame units: both GEMMs + staging/epilogue; one block per CU cannot overlap
+    // its memory phases with another block's MFMA phases
+    const double work = WN * (NF + 1) * 16 + NT + 0.35 * halo1 + 32.0;
+    const double cost = rounds * bpc * work * (bpc == 1 ? 1.3 : 1.0);
+    if (cost < best_cost) { best_cost = cost; best = TileChoice{NF, (int)blocks, lds}; }
+  }
+  return best;
+}
+
+template <typename T, int MF, int NF, int WM>
+inline int launch_pair_one(const PairArgs& a, int batch, size_t lds, hipStream_t stream) {
+  auto kern = rbpair_kernel<T, MF, NF, WM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return QVC_ERR_LAUNCH;
+    attr_done = true;
+  }
+  constexpr int NT = (kWaves / WM) * NF * 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, NT), (unsigned)batch), dim3(256), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+template <typename T, int MF, int WM>
+inline int launch_pair_nf(const ConvDesc& d, const PairArgs& a, int batch, hipStream_t stream, int* nf_out) {
+  const TileChoice tc = choose_pair_tile(d, a.T, batch);
+  if (nf_out) *nf_out = tc.NF;
+  switch (tc.NF) {
+    case 2: return launch_pair_one<T, MF, 2, WM>(a, batch, tc.lds, stream);
+    case 4: return launch_pair_one<T, MF, 4, WM>(a, batch, tc.lds, stream);
+    case 5: return launch_pair_one<T, MF, 5, WM>(a, batch, tc.lds, stream);
+    case 8: if constexpr (MF * 9 * 4 <= 160) return launch_pair_one<T, MF, 8, WM>(a, batch, tc.lds, stream); break;
+    default: break;
+  }
+  return QVC_ERR_BAD_CONFIG;
+}
+
+template <typename T>
+int launch_pair_typed(const ConvDesc& d, const PairArgs& a, int batch, void* stream_v, int* nf_out) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  switch (d.WM * 10 + d.MF) {
+    case 41: return launch_pair_nf<T, 1, 4>(d, a, batch, stream, nf_out);
+    case 42: return launch_pair_nf<T, 2, 4>(d, a, batch, stream, nf_out);
+    case 43: return launch_pair_nf<T, 3, 4>(d, a, batch, stream, nf_out);
+    case 44: return launch_pair_nf<T, 4, 4>(d, a, batch, stream, nf_out);
+    case 23: return launch_pair_nf<T, 3, 2>(d, a, batch, stream, nf_out);
+    case 24: return launch_pair_nf<T, 4, 2>(d, a, batch, stream, nf_out);
+    case 14: return launch_pair_nf<T, 4, 1>(d, a, batch, stream, nf_out);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }

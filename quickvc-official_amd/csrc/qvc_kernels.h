@@ -32,11 +32,25 @@ struct ConvArgs {
   int32_t Nq = 0, up_s = 1, up_p = 0, Cout = 0, T_out = 0;
   // ---- epilogue
   const float* res = nullptr; int64_t res_bs = 0; int32_t res_ts = 0, res_c0 = 0; float res_sign = 1.f;
+  const void* res16 = nullptr;     // residual in the operand type (same strides as res; res_c0 ignored)
   float* y32 = nullptr; int64_t y32_bs = 0; int32_t y32_ts = 0, y32_c0 = 0; float y_scale = 1.f; int32_t y_accum = 0;
   void* y16 = nullptr; int64_t y16_bs = 0; int32_t y16_ts = 0; float slope_out = 1.f;
   // res/skip split (WN 1x1, modules.py:104-112): rows >= split go to y32b[.. v-split] += val
   float* y32b = nullptr; int32_t split = 0;
   int32_t gau_H = 0;       // EPI_GAU: hidden size (rows are [tanh | sigmoid])
+};
+
+// Arguments of one fused ResBlock1 pair (modules.py:148-153):  y = x + conv2(lrelu(conv1(lrelu(x)))).
+// x / y are frame-major tensors in the operand type; with m32 set the result is instead accumulated
+// into the fp32 MRF mean (models.py:378-384):  m32 = (accum ? m32 : 0) + scale * y.
+struct PairArgs {
+  const void* x = nullptr; int64_t bs = 0; int32_t T = 0, C = 0, CP = 0;
+  const void* w1 = nullptr; const float* b1 = nullptr;
+  const void* w2 = nullptr; const float* b2 = nullptr;
+  int32_t k = 1, dil = 1, KS = 1, nIt = 1;
+  float slope = 0.1f;
+  void* y = nullptr;
+  float* m32 = nullptr; float scale = 1.f; int32_t accum = 0;
 };
 
 struct GemvArgs {
@@ -59,11 +73,13 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
 
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
+int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 int launch_gemv(const GemvArgs& a, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
 int launch_tail(const TailArgs& a, void* stream);
 
 // Instantiation entry (one translation unit per operand dtype).
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
+template <typename T> int launch_pair_typed(const ConvDesc& d1, const PairArgs& a, int batch, void* stream, int* nf_out);
 
 }  // namespace qvc

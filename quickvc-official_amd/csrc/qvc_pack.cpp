@@ -109,7 +109,7 @@ struct Packer {
     uint16_t* dst = reinterpret_cast<uint16_t*>(blob + d.w_off);
     const int KS = d.KS(), nIt = d.nIt();
     for (int chunk = 0; chunk < d.nchunk; ++chunk)
-      for (int wave = 0; wave < kWaves; ++wave)
+      for (int wave = 0; wave < d.WM; ++wave)
         for (int it = 0; it < nIt; ++it) {
           const int tap = it / KS, ks = it % KS;
           for (int mf = 0; mf < d.MF; ++mf)

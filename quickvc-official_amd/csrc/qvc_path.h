@@ -7,6 +7,7 @@
 // emulation.
 //
 // A backend provides:  int conv(const ConvDesc&, const ConvArgs&, int batch, int epi, int dtype);
+//                      int pair(const ConvDesc&, const ConvDesc&, const PairArgs&, int batch, int dtype);
 //                      int gemv(const GemvArgs&); int sample(const SampleArgs&);
 //                      int tail(const TailArgs&); int zero(void* ptr, size_t bytes);
 #pragma once
@@ -159,30 +160,45 @@ struct Path {
         else { a.x = wsp<float>(W.m[i - 1]); a.x_kind = XK_F32_FM; a.slope_in = 0.1f; }
         a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in; a.T_in = t_in;
         a.Nq = (t_out - 1 + p) / s + 1; a.T_out = t_out;
-        a.y32 = wsp<float>(W.u[i]); a.y32_bs = bs; a.y32_ts = ch;
+        a.y16 = wsp<void>(W.u[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;   // raw, operand type
         conv(st.up, a);
       }
       for (int j = 0; j < c.n_resblocks; ++j) {
-        const float* src = wsp<float>(W.u[i]);
+        const void* src = wsp<void>(W.u[i]);
         for (int q = 0; q < 3; ++q) {
-          {   // lrelu -> dilated conv -> lrelu (stored already activated, operand type)
-            ConvArgs a = args(st.c1[(size_t)j * 3 + q]);
-            a.x = src; a.x_kind = XK_F32_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out; a.slope_in = 0.1f;
-            a.Nq = t_out; a.T_out = t_out;
-            a.y16 = wsp<void>(W.xt[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 0.1f;
-            conv(st.c1[(size_t)j * 3 + q], a);
+          const ConvDesc& d1 = st.c1[(size_t)j * 3 + q];
+          const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
+          void* dst = q == 0 ? wsp<void>(W.ra[i]) : wsp<void>(W.rb[i]);
+          const bool last = q == 2;          // the last pair of each ResBlock goes straight into the MRF mean
+          const float scale = 1.f / (float)c.n_resblocks;
+          if (pair_supported(d1, d2)) {
+            PairArgs pa;
+            pa.x = src; pa.bs = bs; pa.T = t_out; pa.C = ch; pa.CP = d1.CinP;
+            pa.w1 = blob + d1.w_off; pa.b1 = reinterpret_cast<const float*>(blob + d1.b_off);
+            pa.w2 = blob + d2.w_off; pa.b2 = reinterpret_cast<const float*>(blob + d2.b_off);
+            pa.k = d1.taps; pa.dil = d1.dil; pa.KS = d1.KS(); pa.nIt = d1.nIt(); pa.slope = 0.1f;
+            if (last) { pa.m32 = wsp<float>(W.m[i]); pa.scale = scale; pa.accum = j > 0 ? 1 : 0; }
+            else pa.y = dst;
+            if (status == QVC_OK) status = be.pair(d1, d2, pa, B, dtype());
+          } else {
+            {   // lrelu -> dilated conv -> lrelu (stored already activated)
+              ConvArgs a = args(d1);
+              a.x = src; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out; a.slope_in = 0.1f;
+              a.Nq = t_out; a.T_out = t_out;
+              a.y16 = wsp<void>(W.xt[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 0.1f;
+              conv(d1, a);
+            }
+            {   // conv -> + x
+              ConvArgs a = args(d2);
+              a.x = wsp<void>(W.xt[i]); a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
+              a.Nq = t_out; a.T_out = t_out;
+              a.res16 = src; a.res_bs = bs; a.res_ts = ch;
+              if (last) { a.y32 = wsp<float>(W.m[i]); a.y32_bs = bs; a.y32_ts = ch; a.y_scale = scale; a.y_accum = j > 0 ? 1 : 0; }
+              else { a.y16 = dst; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f; }
+              conv(d2, a);
+            }
           }
-          {   // conv -> + x ; the last pair of each ResBlock goes straight into the MRF mean
-            ConvArgs a = args(st.c2[(size_t)j * 3 + q]);
-            a.x = wsp<void>(W.xt[i]); a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
-            a.Nq = t_out; a.T_out = t_out;
-            a.res = src; a.res_bs = bs; a.res_ts = ch;
-            a.y32_bs = bs; a.y32_ts = ch;
-            if (q < 2) { a.y32 = wsp<float>(W.r[i]); }
-            else { a.y32 = wsp<float>(W.m[i]); a.y_scale = 1.f / (float)c.n_resblocks; a.y_accum = j > 0 ? 1 : 0; }
-            conv(st.c2[(size_t)j * 3 + q], a);
-          }
-          src = wsp<float>(W.r[i]);
+          src = dst;
         }
       }
       t_in = t_out; ch_in = ch;

@@ -25,7 +25,8 @@ enum EpiKind : int32_t { EPI_STD = 0, EPI_GAU = 1, EPI_RESSKIP = 2 };
 struct ConvDesc {
   int32_t M = 0;        // virtual output channels (s*Cout for a polyphase transposed conv)
   int32_t MF = 1;       // A fragments (16 rows) per wave
-  int32_t nchunk = 1;   // M chunks of kWaves*MF*16 rows
+  int32_t WM = 4;       // waves of a workgroup along M (the other kWaves/WM split the frames)
+  int32_t nchunk = 1;   // M chunks of WM*MF*16 rows
   int32_t Cin = 0;      // real input channels
   int32_t CinP = 0;     // padded to a multiple of 32
   int32_t taps = 1, dil = 1, left = 0;
@@ -35,35 +36,61 @@ struct ConvDesc {
   int32_t gau = 0;      // 1: rows permuted so that a wave owns tanh and sigmoid rows of the same channels
   int64_t w_off = 0;    // byte offset of the A stream
   int64_t b_off = 0;    // byte offset of the fp32 bias [MP]
-  int32_t MP() const { return nchunk * kWaves * MF * 16; }
+  int32_t MP() const { return nchunk * WM * MF * 16; }
   int32_t KS() const { return CinP / kKStep; }
   int32_t nIt() const { return taps * KS(); }
-  int64_t w_bytes() const { return (int64_t)nchunk * kWaves * nIt() * MF * kFragElems * 2; }
+  int64_t w_bytes() const { return (int64_t)nchunk * WM * nIt() * MF * kFragElems * 2; }
   int64_t b_bytes() const { return (int64_t)MP() * 4; }
 };
 
 // Row permutation of the A stream: packed position -> original output channel (or -1 = zero padding).
+// `wave` = the wave's index along M (0..WM-1).
 inline int conv_row(const ConvDesc& d, int chunk, int wave, int mf, int i) {
   if (!d.gau) {
-    int v = ((chunk * kWaves + wave) * d.MF + mf) * 16 + i;
+    int v = ((chunk * d.WM + wave) * d.MF + mf) * 16 + i;
     return v < d.M ? v : -1;
   }
-  // GAU: MF == 2, mf 0 = tanh half, mf 1 = sigmoid half, 64 channels per chunk
-  int H = d.M / 2;
-  int ch = chunk * 64 + wave * 16 + i;
-  return ch < H ? mf * H + ch : -1;
+  // GAU: a wave owns MF/2 tanh fragments followed by MF/2 sigmoid fragments of the same channels
+  const int H = d.M / 2, hf = d.MF / 2;
+  const int ch = ((chunk * d.WM + wave) * hf + (mf % hf)) * 16 + i;
+  return ch < H ? (mf / hf) * H + ch : -1;
 }
 
+// Picks fragments-per-wave and the wave grid: least zero padding first, then the largest block
+// (WM*MF rows), then the largest MF (more reuse of every B fragment read from LDS).
 inline void choose_mf(ConvDesc& d) {
-  if (d.gau) { d.MF = 2; d.nchunk = ceil_div(d.M / 2, 64); return; }
-  int best_mf = 1, best_cost = 1 << 30;
-  for (int mf = 1; mf <= 4; ++mf) {
-    int nch = ceil_div(d.M, kWaves * mf * 16);
-    int cost = nch * mf;
-    if (cost < best_cost || (cost == best_cost && mf > best_mf)) { best_cost = cost; best_mf = mf; }
+  if (d.gau) {
+    const int H = d.M / 2;
+    int best_hf = 1; long best_key = -1;
+    for (int hf = 1; hf <= 3; ++hf) {
+      const int nch = ceil_div(H, kWaves * hf * 16);
+      const long key = -(long)(nch * kWaves * hf * 16 - H) * 1000 + hf;
+      if (best_key == -1 || key > best_key) { best_key = key; best_hf = hf; }
+    }
+    d.MF = 2 * best_hf; d.WM = kWaves; d.nchunk = ceil_div(H, kWaves * best_hf * 16);
+    return;
   }
-  d.MF = best_mf;
-  d.nchunk = ceil_div(d.M, kWaves * best_mf * 16);
+  static const int cand[][2] = {{4, 4}, {3, 4}, {2, 4}, {1, 4}, {4, 2}, {3, 2}, {4, 1}};   // {MF, WM} built variants
+  int best = 0; long best_key = 0; bool first = true;
+  for (int c = 0; c < 7; ++c) {
+    const int mf = cand[c][0], wm = cand[c][1];
+    if (mf == 1 && d.M >= 32) continue;
+    const int blockM = wm * mf * 16;
+    const int waste = ceil_div(d.M, blockM) * blockM - d.M;
+    const long key = -(long)waste * 100000 + blockM * 10 + mf;
+    if (first || key > best_key) { best_key = key; best = c; first = false; }
+  }
+  d.MF = cand[best][0]; d.WM = cand[best][1];
+  d.nchunk = ceil_div(d.M, d.WM * d.MF * 16);
+}
+
+// Can the two convs of a ResBlock1 pair run as one fused launch?  (one workgroup must own all channels)
+inline bool pair_supported(const ConvDesc& d1, const ConvDesc& d2) {
+  if (d1.nchunk != 1 || d2.nchunk != 1 || d1.MF != d2.MF || d1.WM != d2.WM) return false;
+  if (d1.M != d2.M || d1.Cin != d1.M || d2.Cin != d2.M || d1.taps != d2.taps || d2.dil != 1 || d1.up_s != 1 || d2.up_s != 1) return false;
+  if (d1.MF * 3 * 4 > 160) return false;
+  const int64_t lds = (int64_t)((kWaves / d1.WM) * 3 * 16 + (d1.taps - 1) * d1.dil) * d1.CinP * 2;   // smallest tile
+  return lds <= 160 * 1024;
 }
 
 struct WNPlan {
@@ -237,7 +264,7 @@ struct Workspace {
   int64_t stats = 0;     // fp32 [B][T][2C]             enc_p.proj output
   int64_t z = 0;         // fp32 [B][T][C]              latent (flow state)
   int64_t c0 = 0;        // op   [B][T][init_ch]        lrelu(conv_pre + cond)
-  std::vector<int64_t> u, r, m, xt;   // per stage: up output, resblock stream, MRF mean (fp32), conv1 output (op)
+  std::vector<int64_t> u, ra, rb, xt, m;   // per stage: up output, ResBlock stream ping/pong, conv1 output (op type); MRF mean (fp32)
   int64_t post = 0;      // fp32 [B][F][post_channels]
   int64_t bytes = 0;
 };
@@ -259,10 +286,11 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
   for (size_t i = 0; i < P.stages.size(); ++i) {
     t *= P.stages[i].rate;
     int64_t n = (int64_t)B * t * P.stages[i].ch;
-    W.u.push_back(take(n * 4));
-    W.r.push_back(take(n * 4));
-    W.m.push_back(take(n * 4));
+    W.u.push_back(take(n * 2));
+    W.ra.push_back(take(n * 2));
+    W.rb.push_back(take(n * 2));
     W.xt.push_back(take(n * 2));
+    W.m.push_back(take(n * 4));
   }
   W.post = take((int64_t)B * (t + 1) * P.post_channels * 4);
   W.bytes = off;

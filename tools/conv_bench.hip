@@ -1,0 +1,102 @@
+// tools/conv_bench.hip -- developer micro-benchmark: times the conv kernel at the shapes of the
+// B=32 x 5 s workload (random data), one line per shape.  Build: see tools/build_conv_bench.sh
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+#include "../quickvc-official_amd/csrc/qvc_kernels.h"
+#include "../quickvc-official_amd/csrc/qvc_pack_util.h"
+using namespace qvc;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Shape { const char* name; int Cin, M, T, k, dil; int kind; /*0 std f32 in->y16, 1 op in -> res+y32, 2 gau, 3 rs */ };
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 32;
+  const int reps = argc > 2 ? atoi(argv[2]) : 20;
+  std::vector<Shape> shapes = {
+    {"s2 c1 k3 d1", 128, 128, 5000, 3, 1, 0}, {"s2 c1 k7 d3", 128, 128, 5000, 7, 3, 0}, {"s2 c1 k11 d5", 128, 128, 5000, 11, 5, 0},
+    {"s2 c2 k3", 128, 128, 5000, 3, 1, 1}, {"s2 c2 k11", 128, 128, 5000, 11, 1, 1},
+    {"s1 c1 k3 d1", 256, 256, 1250, 3, 1, 0}, {"s1 c1 k11 d5", 256, 256, 1250, 11, 5, 0}, {"s1 c2 k7", 256, 256, 1250, 7, 1, 1},
+    {"wn in k5 gau", 192, 384, 250, 5, 1, 2}, {"wn rs 1x1", 192, 384, 250, 1, 1, 3},
+    {"conv_pre k7", 192, 512, 250, 7, 1, 0}, {"post k7 M72", 128, 72, 5001, 7, 1, 1},
+  };
+  hipStream_t st; CK(hipStreamCreate(&st));
+  size_t maxel = (size_t)B * 5001 * 512;
+  float *x32, *y32, *res, *bb; void *x16, *y16;
+  CK(hipMalloc(&x32, maxel * 4)); CK(hipMalloc(&y32, maxel * 4)); CK(hipMalloc(&res, maxel * 4));
+  CK(hipMalloc(&x16, maxel * 2)); CK(hipMalloc(&y16, maxel * 2)); CK(hipMalloc(&bb, 1 << 20));
+  {
+    std::vector<float> h(maxel);
+    for (size_t i = 0; i < maxel; ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 32768.f - 1.f;
+    CK(hipMemcpy(x32, h.data(), maxel * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(res, h.data(), maxel * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> hh(maxel);
+    for (size_t i = 0; i < maxel; ++i) hh[i] = (uint16_t)(0x3000 + ((i * 40503u) & 0x7ff) + ((i & 1) << 15));   // small f16 values
+    CK(hipMemcpy(x16, hh.data(), maxel * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(bb, 0, 1 << 20));
+  }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (const Shape& s : shapes) {
+    ConvDesc d = make_conv(s.M, s.Cin, s.k, s.dil, s.kind == 2);
+    d.w_off = 0; d.b_off = align_up(d.w_bytes(), 256);
+    size_t wb = d.b_off + d.b_bytes();
+    std::vector<char> hw(wb);
+    std::vector<float> w((size_t)s.M * s.Cin * s.k), bias(s.M, 0.01f);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
+    pack_plain_conv(d, w.data(), bias.data(), QVC_F16, hw.data());
+    void* dw; CK(hipMalloc(&dw, wb)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
+    ConvArgs a;
+    a.w = dw; a.bias = (const float*)((char*)dw + d.b_off);
+    a.T_in = s.T; a.Nq = s.T; a.T_out = s.T;
+    int epi = EPI_STD;
+    const int64_t bs_in = (int64_t)s.T * s.Cin, bs_out = (int64_t)s.T * s.M;
+    if (s.kind == 0) { a.x = x32; a.x_kind = XK_F32_FM; a.x_bs = bs_in; a.x_ts = s.Cin; a.slope_in = 0.1f; a.y16 = y16; a.y16_bs = bs_out; a.y16_ts = s.M; a.slope_out = 0.1f; }
+    if (s.kind == 1) { a.x = x16; a.x_kind = XK_OP_FM; a.x_bs = bs_in; a.x_ts = s.Cin; a.res = res; a.res_bs = bs_out; a.res_ts = s.M; a.y32 = y32; a.y32_bs = bs_out; a.y32_ts = s.M; }
+    if (s.kind == 2) { a.x = x32; a.x_kind = XK_F32_FM; a.x_bs = bs_in; a.x_ts = s.Cin; a.bbias = bb; a.bbias_bs = 0; a.gau_H = s.M / 2; a.y16 = y16; a.y16_bs = (int64_t)s.T * s.M / 2; a.y16_ts = s.M / 2; epi = EPI_GAU; }
+    if (s.kind == 3) { a.x = x16; a.x_kind = XK_OP_FM; a.x_bs = bs_in; a.x_ts = s.Cin; a.split = s.M / 2; a.res = res; a.res_bs = (int64_t)s.T * s.M / 2; a.res_ts = s.M / 2; a.y32 = res; a.y32b = y32; a.y32_bs = (int64_t)s.T * s.M / 2; a.y32_ts = s.M / 2; }
+    int nf = 0;
+    for (int i = 0; i < 3; ++i) if (launch_conv(d, a, B, epi, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch failed\n", s.name); break; }
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) launch_conv(d, a, B, epi, QVC_F16, st, &nf);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    const double flops = 2.0 * B * s.T * (double)s.M * s.k * s.Cin;
+    printf("%-14s MF%d WM%d NF%-2d chunks%d  %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d.MF, d.WM, nf, d.nchunk, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
+    CK(hipFree(dw));
+  }
+  // ---- fused ResBlock pairs
+  struct PShape { const char* name; int C, T, k, dil; };
+  std::vector<PShape> pshapes = {{"pair s2 k3 d1", 128, 5000, 3, 1}, {"pair s2 k7 d3", 128, 5000, 7, 3}, {"pair s2 k11 d5", 128, 5000, 11, 5},
+                                 {"pair s1 k3 d1", 256, 1250, 3, 1}, {"pair s1 k7 d3", 256, 1250, 7, 3}, {"pair s1 k11 d5", 256, 1250, 11, 5}};
+  for (const PShape& s : pshapes) {
+    ConvDesc d1 = make_conv(s.C, s.C, s.k, s.dil), d2 = make_conv(s.C, s.C, s.k, 1);
+    d1.w_off = 0; d1.b_off = align_up(d1.w_bytes(), 256);
+    size_t wb = d1.b_off + d1.b_bytes();
+    std::vector<char> hw(wb);
+    std::vector<float> w((size_t)s.C * s.C * s.k), bias(s.C, 0.01f);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
+    pack_plain_conv(d1, w.data(), bias.data(), QVC_F16, hw.data());
+    void* dw; CK(hipMalloc(&dw, wb)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
+    PairArgs a;
+    a.x = x16; a.bs = (int64_t)s.T * s.C; a.T = s.T; a.C = s.C; a.CP = d1.CinP;
+    a.w1 = dw; a.b1 = (const float*)((char*)dw + d1.b_off); a.w2 = dw; a.b2 = a.b1;
+    a.k = s.k; a.dil = s.dil; a.KS = d1.KS(); a.nIt = d1.nIt(); a.y = y16;
+    int nf = 0;
+    for (int i = 0; i < 3; ++i) if (launch_pair(d1, d2, a, B, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch failed\n", s.name); break; }
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    const double flops = 2.0 * 2.0 * B * s.T * (double)s.C * s.k * s.C;
+    printf("%-14s MF%d WM%d NF%-2d          %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d1.MF, d1.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
+    CK(hipFree(dw));
+  }
+  return 0;
+}
