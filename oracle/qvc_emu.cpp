@@ -168,6 +168,61 @@ struct EmuBackend {
     }
   }
 
+  // dense natural-order weights [M][nIt][32] recovered from a fragment stream (any row permutation)
+  static std::vector<float> dense(const ConvDesc& d, const void* w, int dtype) {
+    const int nIt = d.nIt();
+    std::vector<float> W((size_t)d.M * nIt * kKStep, 0.f);
+    const uint16_t* src = static_cast<const uint16_t*>(w);
+    for (int chunk = 0; chunk < d.nchunk; ++chunk)
+      for (int wave = 0; wave < d.WM; ++wave)
+        for (int it = 0; it < nIt; ++it)
+          for (int mf = 0; mf < d.MF; ++mf)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int row = conv_row(d, chunk, wave, mf, lane & 15);
+              if (row < 0) continue;
+              for (int j = 0; j < 8; ++j) {
+                const size_t frag = ((size_t)(chunk * d.WM + wave) * nIt + it) * d.MF + mf;
+                const uint16_t h = src[(frag * 64 + lane) * 8 + j];
+                W[((size_t)row * nIt + it) * kKStep + (lane >> 4) * 8 + j] = dtype == QVC_F16 ? from_f16(h) : from_bf16(h);
+              }
+            }
+    return W;
+  }
+  // fused WaveNet layer, evaluated frame by frame in natural channel order
+  int wn(const ConvDesc& din, const ConvDesc& drs, const WnArgs& a, int B, int dtype) {
+    const std::vector<float> W1 = dense(din, a.w_in, dtype), W2 = dense(drs, a.w_rs, dtype);
+    const int H = a.H, HP = din.CinP, KS = din.KS(), nIt1 = din.nIt(), left = (din.taps - 1) / 2;
+    std::vector<float> xr((size_t)(a.T + din.taps) * HP), acts(HP), pre(2 * H);
+    for (int b = 0; b < B; ++b) {
+      std::fill(xr.begin(), xr.end(), 0.f);
+      for (int t = 0; t < a.T; ++t)
+        for (int c = 0; c < H; ++c) xr[(size_t)(t + left) * HP + c] = round_op(a.x_in[(size_t)b * a.bs + (size_t)t * H + c], dtype);
+      for (int t = 0; t < a.T; ++t) {
+        for (int v = 0; v < 2 * H; ++v) {
+          double acc = 0;
+          for (int it = 0; it < nIt1; ++it) {
+            const int tap = it / KS, ks = it % KS;
+            const float* xrow = &xr[(size_t)(t + tap) * HP + ks * kKStep];
+            const float* wr = &W1[((size_t)v * nIt1 + it) * kKStep];
+            for (int k = 0; k < kKStep; ++k) acc += (double)wr[k] * xrow[k];
+          }
+          pre[v] = (float)acc + a.bbias[(size_t)b * a.bbias_bs + v];
+        }
+        std::fill(acts.begin(), acts.end(), 0.f);
+        for (int c = 0; c < H; ++c) acts[c] = round_op(std::tanh(pre[c]) * (1.f / (1.f + std::exp(-pre[H + c]))), dtype);
+        for (int v = 0; v < drs.M; ++v) {
+          double acc = 0;
+          for (int it = 0; it < KS; ++it)
+            for (int k = 0; k < kKStep; ++k) acc += (double)W2[((size_t)v * KS + it) * kKStep + k] * acts[it * kKStep + k];
+          const float val = (float)acc + a.b_rs[v];
+          const size_t off = (size_t)b * a.bs + (size_t)t * H;
+          if (!a.last && v < H) a.x_out[off + v] = a.x_in[off + v] + val;
+          else a.oacc[off + (a.last ? v : v - H)] += val;
+        }
+      }
+    }
+    return QVC_OK;
+  }
   // fused pair = the two convs back to back with the intermediate rounded to the operand type
   int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& p, int B, int dtype) {
     std::vector<uint16_t> xt((size_t)B * p.bs);

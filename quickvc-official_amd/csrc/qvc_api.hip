@@ -21,6 +21,7 @@ struct HipBackend {
   hipStream_t stream;
   int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) { return launch_conv(d, a, batch, epi, dtype, stream); }
   int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& a, int batch, int dtype) { return launch_pair(d1, d2, a, batch, dtype, stream); }
+  int wn(const ConvDesc& din, const ConvDesc&, const WnArgs& a, int batch, int dtype) { return launch_wn(din, a, batch, dtype, stream); }
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
@@ -72,6 +73,17 @@ struct TimedBackend {
     std::snprintf(name, sizeof(name), "rbpair<%s,MF%d,NF%d,WM%d>", dtype == QVC_F16 ? "f16" : "bf16", d1.MF, nf, d1.WM);
     const double outs = (double)batch * a.T * a.C;
     note(name, 2.0 * 2.0 * outs * a.C * a.k, outs * 2 * 2 + outs * (a.m32 ? (a.accum ? 8 : 4) : 2) + (double)d1.w_bytes() + (double)d2.w_bytes());
+    return st;
+  }
+  int wn(const ConvDesc& din, const ConvDesc& drs, const WnArgs& a, int batch, int dtype) {
+    if (ev.empty()) mark();
+    int nf = 0;
+    int st = launch_wn(din, a, batch, dtype, stream, &nf);
+    mark();
+    char name[48];
+    std::snprintf(name, sizeof(name), "wn_layer<%s,FW%d,NF%d%s>", dtype == QVC_F16 ? "f16" : "bf16", din.MF / 2, nf, a.last ? ",last" : "");
+    const double cols = (double)batch * a.T;
+    note(name, 2.0 * cols * a.H * (2.0 * a.H * a.taps + (double)drs.M), cols * a.H * 4 * (a.last ? 3 : 5) + (double)din.w_bytes() + (double)drs.w_bytes());
     return st;
   }
   int gemv(const GemvArgs& a) { if (ev.empty()) mark(); int st = launch_gemv(a, stream); mark();

@@ -75,25 +75,51 @@ __device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, f
   return r;
 }
 
-constexpr int kPF = 2;   // A fragments are prefetched this many k-steps ahead (register ring of kPF+1)
+// A fragments are prefetched PF k-steps ahead through a register ring of PF+1 slots.  Bytes in flight per
+// wave = PF * MF KiB: the weight stream of a layer is cold (touched once per step), so small-tile kernels
+// (WaveNet layer) need a deep ring to cover the L2/MALL round trip; big-tile kernels are MFMA-paced.
+#ifndef QVC_PF_CONV
+#define QVC_PF_CONV 2
+#endif
+// k-step rotation of a workgroup (see gemm_loop); QVC_NO_ROT=1 disables it for A/B measurements
+// (measured: no effect on gfx950 -- the L2 is not the limiter -- so it is off; QVC_ROTATE=1 enables it)
+#ifdef QVC_ROTATE
+#define QVC_ROT(n) ((int)((blockIdx.x * 5u + blockIdx.y * 3u + blockIdx.z) % (unsigned)(n)))
+#else
+#define QVC_ROT(n) 0
+#endif
+// developer ablation switches for tools/conv_bench (never defined in the product build)
+#ifdef QVC_ABLATE
+#define QVC_ABL(bit) ((QVC_ABLATE >> (bit)) & 1)
+#else
+#define QVC_ABL(bit) 0
+#endif
+#ifndef QVC_PF_WN
+#define QVC_PF_WN 4
+#endif
 
 // The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
 // wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
-template <typename T, int MF, int NF>
+template <typename T, int MF, int NF, int kPF>
 __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
-                                          const char* tile, int rowbytes, Swz sm, int colrow, int lq) {
+                                          const char* tile, int rowbytes, Swz sm, int colrow, int lq, int rot) {
+  // `rot`: this workgroup starts its walk over the k-steps at step `rot` and wraps around.  All
+  // workgroups of a launch stream the SAME weights; started in lockstep they would all hit the same
+  // few L2 channels at every instant.  Rotating the start spreads them over the whole stream.
   using O = Op<T>;
   using frag = typename O::frag;
   constexpr int RING = kPF + 1;
   frag ar[RING][MF];
+  int pf = rot;                                                 // physical k-step of the next prefetch
 #pragma unroll
   for (int u = 0; u < kPF; ++u)
     if (u < nIt) {
 #pragma unroll
-      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)u * MF + m) * 64];
+      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)pf * MF + m) * 64];
+      if (++pf == nIt) pf = 0;
     }
   const int nstride = 16 * rowbytes;
-  int tap = 0, ks = 0;
+  int tap = rot / KS, ks = rot - tap * KS;
   for (int it0 = 0; it0 < nIt; it0 += RING) {
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
@@ -101,7 +127,8 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
       if (it < nIt) {                                           // wave-uniform
         if (it + kPF < nIt) {
 #pragma unroll
-          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)(it + kPF) * MF + m) * 64];
+          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pf * MF + m) * 64];
+          if (++pf == nIt) pf = 0;
         }
         const int row0 = tap * dil + colrow;
         const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
@@ -113,6 +140,7 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
 #pragma unroll
           for (int m = 0; m < MF; ++m) acc[m][n] = O::mfma(ar[u][m], bf[n], acc[m][n]);
         if (++ks == KS) { ks = 0; ++tap; }
+        if (tap * KS + ks == nIt) { tap = 0; ks = 0; }
       }
     }
   }
@@ -236,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   const frag* ap = static_cast<const frag*>(a.w) + ((size_t)(chunk * WM + wm) * a.nIt * MF) * 64 + lane;
   const int lrow = lane & 15, lq = lane >> 4;
-  gemm_loop<T, MF, NF>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq);
+  gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
 
   // ------------------------------------------------------------------ epilogue
   const int qw = q0 + wn * (NF * 16);                           // first frame of this wave's columns
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
   const Swz sm = swz_mode(cpr);
   const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
 
-  {   // ---- stage lrelu(x)
+  if (!QVC_ABL(0)) {   // ---- stage lrelu(x)
     const int t_base = q0 - h2 - h1;
     const int total = Rx * cpr;
     constexpr int kU = 8;
@@ -390,7 +418,7 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
 #pragma unroll
       for (int n = 0; n < NF1; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w1) + ((size_t)wm * a.nIt * MF) * 64 + lane;
-    gemm_loop<T, MF, NF1>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF1 * 16) + lrow, lq);
+    if (!QVC_ABL(1)) gemm_loop<T, MF, NF1, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF1 * 16) + lrow, lq, QVC_ROT(a.nIt));
     __syncthreads();                     // every wave is done reading the input tile
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -422,11 +450,11 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
 #pragma unroll
       for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
-    gemm_loop<T, MF, NF>(acc, ap, a.nIt, a.KS, 1, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq);
+    if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, 1, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       const int v = (wm * MF + m) * 16 + lq * 4;
-      if (v >= a.C) continue;
+      if (v >= a.C || (QVC_ABL(3) && acc[0][0][0] != 12345.f)) continue;
       const float4 bias = *reinterpret_cast<const float4*>(a.b2 + v);
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
@@ -449,6 +477,153 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
           h[0] = O::cvt(val.x); h[1] = O::cvt(val.y); h[2] = O::cvt(val.z); h[3] = O::cvt(val.w);
           *reinterpret_cast<quad*>(static_cast<T*>(a.y) + off) = h;
         }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ fused WaveNet layer
+// FW = tanh (= sigmoid = res = skip) fragments per wave; the 4 waves split the channels, so one
+// workgroup owns ALL 2h gate rows of its NF*16 frames, gates them into an LDS tile and runs the 1x1
+// res/skip GEMM from there: one launch per layer, the gated activations never leave the CU.
+template <typename T, int FW, int NF, bool LAST>
+__global__ __launch_bounds__(256) void wn_layer_kernel(const WnArgs a) {
+  using O = Op<T>;
+  using frag = typename O::frag;
+  using quad = typename O::quad;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NF * 16;
+  constexpr int MF1 = 2 * FW, MF2 = LAST ? FW : 2 * FW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * NT;
+  const int halo = a.taps - 1, left = halo / 2;
+  const int R = NT + halo;
+  const int rowbytes = a.HP * 2;
+  const int cpr = a.HP >> 3;
+  const Swz sm = swz_mode(cpr);
+  char* acts = smem + R * rowbytes;                              // second tile: NT rows of gated activations
+  const float* xb = a.x_in + (size_t)b * a.bs;
+
+  if (!QVC_ABL(0)) {   // ---- stage x (fp32 -> operand type), rows [q0-left, q0-left+R)
+    const int total = R * cpr;
+    constexpr int kU = 4;
+    for (int base = tid; base < total; base += 256 * kU) {
+      float4 v0[kU], v1[kU];
+      int dst[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * 256;
+        const int r = idx / cpr, c8 = idx - r * cpr;
+        const int ti = q0 - left + r;
+        const bool ok = idx < total && ti >= 0 && ti < a.T && (c8 * 8 < a.H);
+        v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
+        if (ok) {
+          const float4* p = reinterpret_cast<const float4*>(xb + (size_t)ti * a.H + c8 * 8);
+          v0[u] = p[0]; v1[u] = p[1];
+        }
+        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (dst[u] < 0) continue;
+        frag h;
+        h[0] = O::cvt(v0[u].x); h[1] = O::cvt(v0[u].y); h[2] = O::cvt(v0[u].z); h[3] = O::cvt(v0[u].w);
+        h[4] = O::cvt(v1[u].x); h[5] = O::cvt(v1[u].y); h[6] = O::cvt(v1[u].z); h[7] = O::cvt(v1[u].w);
+        *reinterpret_cast<frag*>(smem + dst[u]) = h;
+      }
+    }
+  }
+  __syncthreads();
+
+  {   // ---- GEMM1 (k taps) + conditioning + gate -> acts tile
+    f32x4 acc[MF1][NF];
+#pragma unroll
+    for (int m = 0; m < MF1; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const frag* ap = static_cast<const frag*>(a.w_in) + ((size_t)wm * a.nIt1 * MF1) * 64 + lane;
+    if (!QVC_ABL(1)) gemm_loop<T, MF1, NF, QVC_PF_WN>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, QVC_ROT(a.nIt1));
+    const float* bb = a.bbias + (size_t)b * a.bbias_bs;
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const int ch0 = (wm * FW + f) * 16 + lq * 4;
+      if (ch0 >= a.HP) continue;
+      float4 bt = make_float4(0.f, 0.f, 0.f, 0.f), bs = bt;
+      if (ch0 < a.H) { bt = *reinterpret_cast<const float4*>(bb + ch0); bs = *reinterpret_cast<const float4*>(bb + a.H + ch0); }
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int j = n * 16 + lrow;
+        const f32x4 t = acc[f][n], sg = acc[FW + f][n];
+        quad o;
+        if (ch0 < a.H) {
+          o[0] = O::cvt(fast_tanh(t[0] + bt.x) * fast_sigmoid(sg[0] + bs.x));
+          o[1] = O::cvt(fast_tanh(t[1] + bt.y) * fast_sigmoid(sg[1] + bs.y));
+          o[2] = O::cvt(fast_tanh(t[2] + bt.z) * fast_sigmoid(sg[2] + bs.z));
+          o[3] = O::cvt(fast_tanh(t[3] + bt.w) * fast_sigmoid(sg[3] + bs.w));
+        } else {
+          o[0] = o[1] = o[2] = o[3] = (T)0.f;                    // K padding of the 1x1 must be finite
+        }
+        *reinterpret_cast<quad*>(acts + j * rowbytes + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  {   // ---- GEMM2 (1x1) + residual / skip updates
+    f32x4 acc[MF2][NF];
+#pragma unroll
+    for (int m = 0; m < MF2; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const frag* ap = static_cast<const frag*>(a.w_rs) + ((size_t)wm * a.KS * MF2) * 64 + lane;
+    if (!QVC_ABL(2)) gemm_loop<T, MF2, NF, QVC_PF_WN>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, QVC_ROT(a.KS));
+    // all loads of the epilogue are issued before the first dependent store (they are independent
+    // L2 round trips; issued one by one they cost ~5 us per layer)
+    float4 xin[FW][NF], oin[FW][NF];
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const int ch0 = (wm * FW + f) * 16 + lq * 4;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = q0 + n * 16 + lrow;
+        const bool ok = ch0 < a.H && q < a.T && !QVC_ABL(3);
+        const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
+        xin[f][n] = make_float4(0.f, 0.f, 0.f, 0.f); oin[f][n] = xin[f][n];
+        if (ok) {
+          if constexpr (!LAST) xin[f][n] = *reinterpret_cast<const float4*>(a.x_in + off);
+          oin[f][n] = *reinterpret_cast<const float4*>(a.oacc + off);
+        }
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const int ch0 = (wm * FW + f) * 16 + lq * 4;
+      if (ch0 >= a.H || QVC_ABL(3)) continue;
+      const float4 b0 = *reinterpret_cast<const float4*>(a.b_rs + ch0);
+      float4 b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (!LAST) b1 = *reinterpret_cast<const float4*>(a.b_rs + a.H + ch0);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = q0 + n * 16 + lrow;
+        if (q >= a.T) continue;
+        const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
+        float4 sk;
+        if constexpr (!LAST) {
+          const float4 xi = xin[f][n];
+          *reinterpret_cast<float4*>(a.x_out + off) = make_float4(xi.x + acc[f][n][0] + b0.x, xi.y + acc[f][n][1] + b0.y,
+                                                                  xi.z + acc[f][n][2] + b0.z, xi.w + acc[f][n][3] + b0.w);
+          sk = make_float4(acc[FW + f][n][0] + b1.x, acc[FW + f][n][1] + b1.y, acc[FW + f][n][2] + b1.z, acc[FW + f][n][3] + b1.w);
+        } else {
+          sk = make_float4(acc[f][n][0] + b0.x, acc[f][n][1] + b0.y, acc[f][n][2] + b0.z, acc[f][n][3] + b0.w);
+        }
+        float4 o = oin[f][n];
+        o.x += sk.x; o.y += sk.y; o.z += sk.z; o.w += sk.w;
+        *reinterpret_cast<float4*>(a.oacc + off) = o;
       }
     }
   }
@@ -597,6 +772,38 @@ int launch_pair_typed(const ConvDesc& d, const PairArgs& a, int batch, void* str
     case 23: return launch_pair_nf<T, 3, 2>(d, a, batch, stream, nf_out);
     case 24: return launch_pair_nf<T, 4, 2>(d, a, batch, stream, nf_out);
     case 14: return launch_pair_nf<T, 4, 1>(d, a, batch, stream, nf_out);
+    default: return QVC_ERR_BAD_CONFIG;
+  }
+}
+
+// ---- fused WaveNet layer dispatch
+template <typename T, int FW, int NF>
+inline int launch_wn_one(const WnArgs& a, int batch, hipStream_t stream) {
+  const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
+  dim3 grid((unsigned)ceil_div(a.T, NF * 16), (unsigned)batch);
+  if (a.last) hipLaunchKernelGGL((wn_layer_kernel<T, FW, NF, true>), grid, dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((wn_layer_kernel<T, FW, NF, false>), grid, dim3(256), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream_v, int* nf_out) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  // 32-frame tiles unless that leaves most CUs without a workgroup anyway and 64 halves the weight traffic
+  const long blocks32 = (long)ceil_div(a.T, 32) * batch;
+  const int NF = blocks32 >= 512 ? 4 : 2;
+  if (nf_out) *nf_out = NF;
+  const int FW = din.MF / 2;
+  if (din.WM != 4 || din.nchunk != 1) return QVC_ERR_BAD_CONFIG;
+  switch (FW * 10 + NF) {
+    case 12: return launch_wn_one<T, 1, 2>(a, batch, stream);
+    case 14: return launch_wn_one<T, 1, 4>(a, batch, stream);
+    case 22: return launch_wn_one<T, 2, 2>(a, batch, stream);
+    case 24: return launch_wn_one<T, 2, 4>(a, batch, stream);
+    case 32: return launch_wn_one<T, 3, 2>(a, batch, stream);
+    case 34: return launch_wn_one<T, 3, 4>(a, batch, stream);
+    case 42: return launch_wn_one<T, 4, 2>(a, batch, stream);
+    case 44: return launch_wn_one<T, 4, 4>(a, batch, stream);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }

@@ -53,6 +53,18 @@ struct PairArgs {
   float* m32 = nullptr; float scale = 1.f; int32_t accum = 0;
 };
 
+// One fused WaveNet layer (modules.py:87-112): k-tap conv h->2h + conditioning + tanh*sigmoid gate, then the
+// 1x1 h->2h whose first half is added to the residual stream x and second half to the skip accumulator
+// (all of it to the accumulator on the last layer).  x is ping-ponged (x_in -> x_out) because neighbouring
+// workgroups read each other's halo frames; oacc is updated in place.
+struct WnArgs {
+  const float* x_in = nullptr; float* x_out = nullptr; float* oacc = nullptr;
+  int64_t bs = 0; int32_t T = 0, H = 0, HP = 0;
+  const void* w_in = nullptr; const void* w_rs = nullptr; const float* b_rs = nullptr;
+  const float* bbias = nullptr; int64_t bbias_bs = 0;
+  int32_t taps = 1, KS = 1, nIt1 = 1, last = 0;
+};
+
 struct GemvArgs {
   const float* w; const float* bias; const float* g; float* out;
   int32_t rows, gin, batch;
@@ -74,12 +86,14 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
+int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 int launch_gemv(const GemvArgs& a, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
 int launch_tail(const TailArgs& a, void* stream);
 
 // Instantiation entry (one translation unit per operand dtype).
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
+template <typename T> int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream, int* nf_out);
 template <typename T> int launch_pair_typed(const ConvDesc& d1, const PairArgs& a, int batch, void* stream, int* nf_out);
 
 }  // namespace qvc

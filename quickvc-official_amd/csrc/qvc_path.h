@@ -8,6 +8,7 @@
 //
 // A backend provides:  int conv(const ConvDesc&, const ConvArgs&, int batch, int epi, int dtype);
 //                      int pair(const ConvDesc&, const ConvDesc&, const PairArgs&, int batch, int dtype);
+//                      int wn(const ConvDesc& in, const ConvDesc& rs, const WnArgs&, int batch, int dtype);
 //                      int gemv(const GemvArgs&); int sample(const SampleArgs&);
 //                      int tail(const TailArgs&); int zero(void* ptr, size_t bytes);
 #pragma once
@@ -61,28 +62,18 @@ struct Path {
     const int64_t bs = (int64_t)T * H;
     zero(W.oacc, (int64_t)B * bs * 4);
     for (int l = 0; l < wn.layers; ++l) {
-      {   // k-tap conv h->2h + conditioning + tanh*sigmoid gate  (modules.py:91-101)
-        ConvArgs a = args(wn.in_conv[l]);
-        a.x = wsp<float>(W.xw); a.x_kind = XK_F32_FM; a.x_bs = bs; a.x_ts = H; a.T_in = T;
-        a.Nq = T; a.T_out = T;
-        a.bbias = bb + (int64_t)l * 2 * H; a.bbias_bs = bb_bs; a.gau_H = H;
-        a.y16 = wsp<void>(W.acts); a.y16_bs = bs; a.y16_ts = H;
-        conv(wn.in_conv[l], a, EPI_GAU);
-      }
-      {   // 1x1 h->2h: x += first half, out += second half (everything on the last layer)  (:104-112)
-        ConvArgs a = args(wn.rs_conv[l]);
-        a.x = wsp<void>(W.acts); a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = H; a.T_in = T;
-        a.Nq = T; a.T_out = T;
-        a.y32b = wsp<float>(W.oacc); a.y32_bs = bs; a.y32_ts = H;
-        if (l < wn.layers - 1) {
-          a.split = H;
-          a.res = wsp<float>(W.xw); a.res_bs = bs; a.res_ts = H;
-          a.y32 = wsp<float>(W.xw);
-        } else {
-          a.split = 0;
-        }
-        conv(wn.rs_conv[l], a);
-      }
+      const ConvDesc& din = wn.in_conv[l];
+      const ConvDesc& drs = wn.rs_conv[l];
+      WnArgs a;
+      a.x_in = wsp<float>(l % 2 == 0 ? W.xw : W.xw2);
+      a.x_out = wsp<float>(l % 2 == 0 ? W.xw2 : W.xw);
+      a.oacc = wsp<float>(W.oacc);
+      a.bs = bs; a.T = T; a.H = H; a.HP = din.CinP;
+      a.w_in = blob + din.w_off; a.w_rs = blob + drs.w_off;
+      a.b_rs = reinterpret_cast<const float*>(blob + drs.b_off);
+      a.bbias = bb + (int64_t)l * 2 * H; a.bbias_bs = bb_bs;
+      a.taps = din.taps; a.KS = din.KS(); a.nIt1 = din.nIt(); a.last = l == wn.layers - 1 ? 1 : 0;
+      if (status == QVC_OK) status = be.wn(din, drs, a, B, dtype());
     }
   }
 

@@ -62,7 +62,7 @@ inline void choose_mf(ConvDesc& d) {
   if (d.gau) {
     const int H = d.M / 2;
     int best_hf = 1; long best_key = -1;
-    for (int hf = 1; hf <= 3; ++hf) {
+    for (int hf = 1; hf <= 4; ++hf) {
       const int nch = ceil_div(H, kWaves * hf * 16);
       const long key = -(long)(nch * kWaves * hf * 16 - H) * 1000 + hf;
       if (best_key == -1 || key > best_key) { best_key = key; best_hf = hf; }
@@ -141,6 +141,7 @@ inline int validate(const qvc_config& c) {
   auto bad = [](bool cond) { return cond; };
   if (bad(c.unit_channels <= 0 || c.inter_channels <= 0 || c.hidden_channels <= 0 || c.gin_channels <= 0)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.inter_channels % 8 || c.hidden_channels % 8 || c.unit_channels % 8)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.hidden_channels > 256)) return QVC_ERR_BAD_CONFIG;   // one workgroup owns all WN channels (4 waves x 4 x 16)
   if (bad(c.wn_kernel_size < 1 || c.wn_kernel_size % 2 == 0 || c.wn_kernel_size > 15)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.enc_layers < 1 || c.enc_layers > 64 || c.flow_layers < 1 || c.flow_layers > 64)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.n_flows < 1 || c.n_flows > 16 || c.n_flows % 2)) return QVC_ERR_BAD_CONFIG;   // flips must cancel
@@ -200,7 +201,10 @@ inline Plan build_plan(const qvc_config& c) {
       ConvDesc a = make_conv(2 * H, H, K, 1, /*gau=*/true);
       place(a, /*with_bias=*/false);
       w.in_conv.push_back(a);
-      ConvDesc r = make_conv(i < layers - 1 ? 2 * H : H, H, 1, 1);
+      // 1x1 res/skip: rows paired like the gate rows ([res | skip] of the same channels per wave) so
+      // that the fused layer kernel updates x and the skip accumulator for the channels it owns
+      ConvDesc r = make_conv(i < layers - 1 ? 2 * H : H, H, 1, 1, /*gau=*/i < layers - 1);
+      if (i == layers - 1) { r.MF = a.MF / 2; r.WM = kWaves; r.nchunk = 1; }
       place(r);
       w.rs_conv.push_back(r);
     }
@@ -258,7 +262,8 @@ inline Plan build_plan(const qvc_config& c) {
 // ---------------------------------------------------------------- workspace carve-up
 struct Workspace {
   int64_t bb = 0;        // fp32 [B][cond_rows]         cond GEMV output (+ folded biases)
-  int64_t xw = 0;        // fp32 [B][T][H]              WN residual stream
+  int64_t xw = 0;        // fp32 [B][T][H]              WN residual stream (ping)
+  int64_t xw2 = 0;       // fp32 [B][T][H]              WN residual stream (pong)
   int64_t oacc = 0;      // fp32 [B][T][H]              WN skip accumulator
   int64_t acts = 0;      // op   [B][T][H]              gated activations
   int64_t stats = 0;     // fp32 [B][T][2C]             enc_p.proj output
@@ -277,6 +282,7 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
   const int64_t BT = (int64_t)B * T;
   W.bb = take((int64_t)B * P.cond_rows * 4);
   W.xw = take(BT * c.hidden_channels * 4);
+  W.xw2 = take(BT * c.hidden_channels * 4);
   W.oacc = take(BT * c.hidden_channels * 4);
   W.acts = take(BT * c.hidden_channels * 2);
   W.stats = take(BT * 2 * c.inter_channels * 4);

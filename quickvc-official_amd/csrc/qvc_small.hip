@@ -227,6 +227,12 @@ int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, vo
   return QVC_ERR_BAD_ARG;
 }
 
+int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream, int* nf_out) {
+  if (dtype == QVC_F16) return launch_wn_typed<_Float16>(din, a, batch, stream, nf_out);
+  if (dtype == QVC_BF16) return launch_wn_typed<__bf16>(din, a, batch, stream, nf_out);
+  return QVC_ERR_BAD_ARG;
+}
+
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out) {
   if (!pair_supported(d1, d2)) return QVC_ERR_BAD_CONFIG;
   if (dtype == QVC_F16) return launch_pair_typed<_Float16>(d1, a, batch, stream, nf_out);

@@ -219,7 +219,9 @@ def test_timed_variant_reports_every_launch(lib, dev):
     assert torch.equal(out, ref)
     names = [r["name"] for r in recs]
     assert names.count("istft_synth") == 1 and names.count("cond_gemv") == 1
-    # enc: pre + 16x2 + proj; flow: 4 x (pre + 4x2 + post); dec: conv_pre + 2 ups + conv_post; 2 x 9 fused ResBlock pairs
-    assert sum(n.startswith("conv<") for n in names) == 1 + 32 + 1 + 4 * (2 + 8) + 1 + 2 + 1
+    # enc: pre + proj; flow: 4 x (pre + post); dec: conv_pre + 2 ups + conv_post; 16 + 4x4 fused WN layers;
+    # 2 x 9 fused ResBlock pairs
+    assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2 + 1
+    assert sum(n.startswith("wn_layer<") for n in names) == 32
     assert sum(n.startswith("rbpair<") for n in names) == 18
     assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0

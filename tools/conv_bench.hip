@@ -69,6 +69,31 @@ int main(int argc, char** argv) {
     printf("%-14s MF%d WM%d NF%-2d chunks%d  %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d.MF, d.WM, nf, d.nchunk, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
+  {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
+    const int H = 192, T = 250, L = 16;
+    ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
+    din.w_off = 0; drs.w_off = align_up(din.w_bytes(), 256); drs.b_off = drs.w_off + align_up(drs.w_bytes(), 256);
+    const size_t per = drs.b_off + align_up(drs.b_bytes(), 256);
+    std::vector<char> hw(per * L, 0);
+    for (size_t i = 0; i < per * L; i += 2) { hw[i] = (char)((i * 131) & 0x7f); hw[i + 1] = (char)(0x20 + ((i >> 3) & 7)); }   // small f16 values
+    void* dw; CK(hipMalloc(&dw, per * L)); CK(hipMemcpy(dw, hw.data(), per * L, hipMemcpyHostToDevice));
+    // evict caches between timed loops with a big memset
+    WnArgs a; a.bs = (int64_t)T * H; a.T = T; a.H = H; a.HP = din.CinP; a.bbias = bb; a.bbias_bs = 0;
+    a.taps = 5; a.KS = din.KS(); a.nIt1 = din.nIt(); a.last = 0; a.oacc = y32;
+    int nf = 0;
+    auto run = [&]() { for (int l = 0; l < L; ++l) { a.x_in = l % 2 ? res : x32; a.x_out = l % 2 ? x32 : res;
+        a.w_in = (char*)dw + per * l; a.w_rs = (char*)dw + per * l + drs.w_off; a.b_rs = (const float*)((char*)dw + per * l + drs.b_off);
+        launch_wn(din, a, B, QVC_F16, st, &nf); } };
+    run(); CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) run();
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps / L;
+    const double flops = 2.0 * B * T * (double)H * (2.0 * H * 5 + 2.0 * H);
+    printf("%-14s FW%d NF%-2d               %8.1f us/layer  %7.1f TF  (%.1f%% of 2.5PF)\n", "wn layer x16", din.MF / 2, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
+    CK(hipFree(dw));
+  }
   // ---- fused ResBlock pairs
   struct PShape { const char* name; int C, T, k, dil; };
   std::vector<PShape> pshapes = {{"pair s2 k3 d1", 128, 5000, 3, 1}, {"pair s2 k7 d3", 128, 5000, 7, 3}, {"pair s2 k11 d5", 128, 5000, 11, 5},
