@@ -133,6 +133,20 @@ int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev,
                     int32_t batch, int32_t frames,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- optional fork/join resources: lets the three independent ResBlocks of an MRF stage
+ * (models.py:378-384) run as parallel branches (two auxiliary non-blocking streams + events), so a
+ * memory-bound k=3 launch overlaps a compute-bound k=11 launch.  Created/destroyed by the caller
+ * outside the hot call; with aux == NULL everything runs on `stream` in the same order.  Works under
+ * hipGraph capture of `stream` (the branches become parallel graph nodes).
+ */
+typedef struct qvc_aux qvc_aux;
+int qvc_aux_create(qvc_aux** out);
+int qvc_aux_destroy(qvc_aux* aux);
+int qvc_infer_batch_ex(const qvc_config* cfg, const void* blob_dev,
+                       const float* unit, const float* g, const float* noise, float* out,
+                       int32_t batch, int32_t frames,
+                       void* workspace, int64_t workspace_bytes, void* stream, qvc_aux* aux);
+
 /* ---- the same call with per-launch timing (diagnostics for bench.py's roofline leg) ----
  * Runs the identical launch sequence but brackets every launch with HIP events recorded on
  * `stream`, synchronises the stream at the end and fills `records` (at most max_records;

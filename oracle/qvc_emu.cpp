@@ -60,6 +60,7 @@ float round_op(float f, int dtype) {
 float lrelu(float x, float s) { return x > 0.f ? x : x * s; }
 
 struct EmuBackend {
+  void fork(int) {} void branch(int) {} void branch_done(int) {} void wait_branch_done(int) {} void join(int) {}
   // ---- conv: dense weights are recovered from the fragment stream with the kernel's index math
   int conv(const ConvDesc& d, const ConvArgs& a, int B, int epi, int dtype) {
     const int KS = d.KS(), nIt = d.nIt(), MP = d.MP();
@@ -220,6 +221,22 @@ struct EmuBackend {
           else a.oacc[off + (a.last ? v : v - H)] += val;
         }
       }
+    }
+    return QVC_OK;
+  }
+  bool use_wn_stack(int, int) const { return true; }
+  // whole stack = the layers one after the other (x ping-pong in temporaries)
+  int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& s, int B, int dtype) {
+    std::vector<float> xa(s.x0, s.x0 + (size_t)B * s.bs), xb((size_t)B * s.bs, 0.f);
+    std::memset(s.out, 0, (size_t)B * s.bs * 4);
+    for (int l = 0; l < s.layers; ++l) {
+      WnArgs a;
+      a.x_in = (l % 2 ? xb : xa).data(); a.x_out = (l % 2 ? xa : xb).data(); a.oacc = s.out;
+      a.bs = s.bs; a.T = s.T; a.H = s.H; a.HP = s.HP;
+      a.w_in = s.w_in[l]; a.w_rs = s.w_rs[l]; a.b_rs = s.b_rs[l];
+      a.bbias = s.bbias + (size_t)l * 2 * s.H; a.bbias_bs = s.bbias_bs;
+      a.taps = s.taps; a.KS = s.KS; a.nIt1 = s.nIt1; a.last = l == s.layers - 1;
+      wn(din, a.last ? drs_last : drs, a, B, dtype);
     }
     return QVC_OK;
   }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 #include "qvc_path.h"
 #include "qvc_pack_util.h"
@@ -14,14 +15,54 @@ namespace qvc {
 int launch_fm_to_cm(const float* src, float* dst, int batch, int frames, int channels, void* stream);
 }
 
+struct qvc_aux {
+  hipStream_t streams[2];
+  hipEvent_t fork, done[3];
+};
+
 namespace {
 using namespace qvc;
 
+// Stream fork/join for the parallel ResBlock branches (branch 0 = the caller's stream).
+struct Branches {
+  hipStream_t main = nullptr;
+  qvc_aux* aux = nullptr;
+  hipStream_t cur = nullptr;
+  bool ok = true;
+  hipStream_t of(int j) const { return (aux && j >= 1 && j <= 2) ? aux->streams[j - 1] : main; }
+  void fork(int n) {
+    cur = main;
+    if (!aux) return;
+    if (hipEventRecord(aux->fork, main) != hipSuccess) ok = false;
+    for (int j = 1; j < n && j <= 2; ++j) if (hipStreamWaitEvent(aux->streams[j - 1], aux->fork, 0) != hipSuccess) ok = false;
+  }
+  void branch(int j) { cur = of(j); }
+  void branch_done(int j) { if (aux && j < 3 && hipEventRecord(aux->done[j], of(j)) != hipSuccess) ok = false; }
+  void wait_branch_done(int j) { if (aux && j < 3 && hipStreamWaitEvent(cur, aux->done[j], 0) != hipSuccess) ok = false; }
+  void join(int n) {
+    if (aux) {   // the mean updates are chained, so the last branch finishing implies all of them; branches > 2 ran on main
+      const int lastb = n - 1 <= 2 ? n - 1 : 2;
+      if (lastb >= 1 && hipStreamWaitEvent(main, aux->done[lastb], 0) != hipSuccess) ok = false;
+    }
+    cur = main;
+  }
+};
+
 struct HipBackend {
   hipStream_t stream;
+  Branches br;
+  void fork(int n) { br.main = stream0; br.fork(n); stream = br.cur; }
+  void branch(int j) { br.branch(j); stream = br.cur; }
+  void branch_done(int j) { br.branch_done(j); }
+  void wait_branch_done(int j) { br.wait_branch_done(j); }
+  void join(int n) { br.join(n); stream = stream0; }
+  hipStream_t stream0 = nullptr;
   int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) { return launch_conv(d, a, batch, epi, dtype, stream); }
   int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& a, int batch, int dtype) { return launch_pair(d1, d2, a, batch, dtype, stream); }
   int wn(const ConvDesc& din, const ConvDesc&, const WnArgs& a, int batch, int dtype) { return launch_wn(din, a, batch, dtype, stream); }
+  // the stack kernel trades 3x recomputed halo for one launch: right when its grid fills the machine
+  bool use_wn_stack(int batch, int frames) const { return (long)batch * ceil_div(frames, kWnOutFrames) >= 128; }
+  int wn_stack(const ConvDesc& din, const ConvDesc&, const ConvDesc&, const WnStackArgs& a, int batch, int dtype) { return launch_wn_stack(din, a, batch, dtype, stream); }
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
@@ -31,6 +72,7 @@ using Ctx = Path<HipBackend>;
 
 // Same launches, each bracketed by events on the stream (diagnostics only).
 struct TimedBackend {
+  void fork(int) {} void branch(int) {} void branch_done(int) {} void wait_branch_done(int) {} void join(int) {}
   hipStream_t stream;
   qvc_launch_record* rec; int max_rec; int n = 0;
   std::vector<hipEvent_t> ev;
@@ -84,6 +126,18 @@ struct TimedBackend {
     std::snprintf(name, sizeof(name), "wn_layer<%s,FW%d,NF%d%s>", dtype == QVC_F16 ? "f16" : "bf16", din.MF / 2, nf, a.last ? ",last" : "");
     const double cols = (double)batch * a.T;
     note(name, 2.0 * cols * a.H * (2.0 * a.H * a.taps + (double)drs.M), cols * a.H * 4 * (a.last ? 3 : 5) + (double)din.w_bytes() + (double)drs.w_bytes());
+    return st;
+  }
+  bool use_wn_stack(int batch, int frames) const { return (long)batch * ceil_div(frames, kWnOutFrames) >= 128; }
+  int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& a, int batch, int dtype) {
+    if (ev.empty()) mark();
+    int st = launch_wn_stack(din, a, batch, dtype, stream);
+    mark();
+    char name[48];
+    std::snprintf(name, sizeof(name), "wn_stack<%s,FW%d,L%d>", dtype == QVC_F16 ? "f16" : "bf16", din.MF / 2, a.layers);
+    const double cols = (double)batch * a.T;
+    const double fl = 2.0 * cols * a.H * (a.layers * 2.0 * a.H * a.taps + (a.layers - 1) * (double)drs.M + (double)drs_last.M);
+    note(name, fl, cols * a.H * 8 + a.layers * ((double)din.w_bytes() + (double)drs.w_bytes()));
     return st;
   }
   int gemv(const GemvArgs& a) { if (ev.empty()) mark(); int st = launch_gemv(a, stream); mark();
@@ -154,21 +208,49 @@ int64_t qvc_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t frames
   return carve_workspace(P, batch, frames).bytes;
 }
 
+int qvc_aux_create(qvc_aux** out) {
+  if (!out) return QVC_ERR_BAD_ARG;
+  qvc_aux* a = new (std::nothrow) qvc_aux();
+  if (!a) return QVC_ERR_BAD_ARG;
+  bool ok = true;
+  for (auto& s : a->streams) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess;
+  for (auto& e : a->done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { delete a; return QVC_ERR_LAUNCH; }
+  *out = a;
+  return QVC_OK;
+}
+
+int qvc_aux_destroy(qvc_aux* a) {
+  if (!a) return QVC_ERR_BAD_ARG;
+  for (auto& s : a->streams) hipStreamDestroy(s);
+  hipEventDestroy(a->fork);
+  for (auto& e : a->done) hipEventDestroy(e);
+  delete a;
+  return QVC_OK;
+}
+
 int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,
                     const float* noise, float* out, int32_t batch, int32_t frames, void* workspace,
                     int64_t workspace_bytes, void* stream) {
+  return qvc_infer_batch_ex(cfg, blob_dev, unit, g, noise, out, batch, frames, workspace, workspace_bytes, stream, nullptr);
+}
+
+int qvc_infer_batch_ex(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,
+                       const float* noise, float* out, int32_t batch, int32_t frames, void* workspace,
+                       int64_t workspace_bytes, void* stream, qvc_aux* aux) {
   if (!unit || !g || !noise || !out) return QVC_ERR_BAD_ARG;
   Plan P; Workspace W;
   int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
   if (st != QVC_OK) return st;
-  HipBackend be{static_cast<hipStream_t>(stream)};
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream); be.br.aux = aux;
   Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
   c.cond_table(g);
   c.enc_p(unit, noise, c.wsp<float>(W.z));
   c.flow(c.wsp<float>(W.z));
   c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
   c.tail(c.wsp<float>(W.post), out, nullptr, frames * P.total_up + 1);
-  return c.status;
+  return c.status != QVC_OK ? c.status : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
 }
 
 int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,
@@ -197,7 +279,7 @@ int qvc_enc_p(const qvc_config* cfg, const void* blob_dev, const float* unit, co
   Plan P; Workspace W;
   int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
   if (st != QVC_OK) return st;
-  HipBackend be{static_cast<hipStream_t>(stream)};
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
   Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
   c.enc_p(unit, noise, z_p_fm);
   return c.status;
@@ -209,7 +291,7 @@ int qvc_flow_reverse(const qvc_config* cfg, const void* blob_dev, float* z_fm, c
   Plan P; Workspace W;
   int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
   if (st != QVC_OK) return st;
-  HipBackend be{static_cast<hipStream_t>(stream)};
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
   Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
   c.cond_table(g);
   c.flow(z_fm);
@@ -222,7 +304,7 @@ int qvc_dec_trunk(const qvc_config* cfg, const void* blob_dev, const float* z_fm
   Plan P; Workspace W;
   int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
   if (st != QVC_OK) return st;
-  HipBackend be{static_cast<hipStream_t>(stream)};
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
   Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
   c.cond_table(g);
   c.dec_trunk(z_fm, post_fm);

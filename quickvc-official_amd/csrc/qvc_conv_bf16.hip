@@ -1,5 +1,6 @@
 // bf16-operand instantiation of the conv kernel.
 #include "qvc_conv_impl.h"
 namespace qvc { template int launch_conv_typed<__bf16>(const ConvDesc&, const ConvArgs&, int, int, void*, int*);
+template int launch_wn_stack_typed<__bf16>(const ConvDesc&, const WnStackArgs&, int, void*);
 template int launch_wn_typed<__bf16>(const ConvDesc&, const WnArgs&, int, void*, int*);
 template int launch_pair_typed<__bf16>(const ConvDesc&, const PairArgs&, int, void*, int*); }

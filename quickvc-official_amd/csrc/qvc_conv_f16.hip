@@ -2,5 +2,6 @@
 // types compile in parallel).
 #include "qvc_conv_impl.h"
 namespace qvc { template int launch_conv_typed<_Float16>(const ConvDesc&, const ConvArgs&, int, int, void*, int*);
+template int launch_wn_stack_typed<_Float16>(const ConvDesc&, const WnStackArgs&, int, void*);
 template int launch_wn_typed<_Float16>(const ConvDesc&, const WnArgs&, int, void*, int*);
 template int launch_pair_typed<_Float16>(const ConvDesc&, const PairArgs&, int, void*, int*); }

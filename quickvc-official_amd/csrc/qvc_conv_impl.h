@@ -48,10 +48,14 @@ template <> struct Op<__bf16> {
 };
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
-__device__ __forceinline__ float fast_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+// Gate math on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32 are 1-ulp instructions;
+// an IEEE division costs ~10 VALU instructions and made the gate as expensive as the layer's MFMAs.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float fast_tanh(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, ~1e-7 abs error elsewhere
-  return 1.f - 2.f / (__expf(2.f * x) + 1.f);
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf (rcp(inf) = 0), ~2e-7 abs error elsewhere
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.f);
 }
 
 // 16-byte-chunk swizzle of a tile row: chunk ^= (row >> sh) & mask, branch-free.  The three modes
@@ -100,12 +104,15 @@ __device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, f
 
 // The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
 // wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
+// The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
+// wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
+// A fragments go through a register ring, prefetched kPF k-steps ahead with plain loads (hipcc tracks
+// them).  An inline-asm variant with hand-counted vmcnt waits was tried and rejected: no faster, and
+// the compiler copied not-yet-landed asm outputs in one instantiation (wrong results).
 template <typename T, int MF, int NF, int kPF>
 __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
                                           const char* tile, int rowbytes, Swz sm, int colrow, int lq, int rot) {
-  // `rot`: this workgroup starts its walk over the k-steps at step `rot` and wraps around.  All
-  // workgroups of a launch stream the SAME weights; started in lockstep they would all hit the same
-  // few L2 channels at every instant.  Rotating the start spreads them over the whole stream.
+  // `rot`: optional rotated start of the walk over the k-steps (QVC_ROTATE, off by default)
   using O = Op<T>;
   using frag = typename O::frag;
   constexpr int RING = kPF + 1;
@@ -629,6 +636,171 @@ __global__ __launch_bounds__(256) void wn_layer_kernel(const WnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ whole WaveNet stack, one launch
+template <typename T, int FW, int NF>
+__global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
+  using O = Op<T>;
+  using frag = typename O::frag;
+  using quad = typename O::quad;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NB = NF * 16;                 // frames carried by this workgroup (output tile + halo)
+  constexpr int MF = 2 * FW;
+  // the skip sum is only needed for the column fragments that overlap the 32 output frames
+  constexpr int OLO = NF > 3 ? 1 : 0, ON = 3;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * kWnOutFrames;
+  const int left = (a.taps - 1) / 2;
+  const int halo = left * a.layers;
+  const int w0 = q0 - halo;                   // first frame of the window; column j <-> frame w0 + j
+  const int rowbytes = a.HP * 2;
+  const int cpr = a.HP >> 3;
+  const Swz sm = swz_mode(cpr);
+  const int R = NB + a.taps - 1;              // x tile rows; row r <-> frame w0 - left + r
+  char* acts = smem + R * rowbytes;
+
+  // zero the x tile once: rows outside the window and K-padding channels must stay finite zeros
+  for (int i = tid; i < (R * rowbytes) >> 4; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  // x residual stream and skip sum of this wave's channels live in registers for the whole stack
+  f32x4 xr[FW][NF], outr[FW][ON];
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    const int ch0 = (wm * FW + f) * 16 + lq * 4;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      const int q = w0 + n * 16 + lrow;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ch0 < a.H && q >= 0 && q < a.T) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
+      xr[f][n] = f32x4{v.x, v.y, v.z, v.w};
+      if (n >= OLO && n < OLO + ON) outr[f][n - OLO] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();                            // tile zeroed before anybody writes x into it
+  auto put_x = [&]() {
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const int ch0 = (wm * FW + f) * 16 + lq * 4;
+      if (ch0 >= a.H) continue;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int r = n * 16 + lrow + left;
+        quad h;
+        h[0] = O::cvt(xr[f][n][0]); h[1] = O::cvt(xr[f][n][1]); h[2] = O::cvt(xr[f][n][2]); h[3] = O::cvt(xr[f][n][3]);
+        *reinterpret_cast<quad*>(smem + r * rowbytes + (((ch0 >> 3) ^ swz(r, sm)) << 4) + (ch0 & 7) * 2) = h;
+      }
+    }
+  };
+  put_x();
+  __syncthreads();
+
+  for (int l = 0; l < a.layers; ++l) {
+    const bool last = l == a.layers - 1;
+    {   // ---- GEMM1 (k taps) + conditioning + gate -> acts tile
+      f32x4 acc[MF][NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const frag* ap = static_cast<const frag*>(a.w_in[l]) + ((size_t)wm * a.nIt1 * MF) * 64 + lane;
+      gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, 0);
+      const float* bb = a.bbias + (size_t)b * a.bbias_bs + (size_t)l * 2 * a.H;
+#pragma unroll
+      for (int f = 0; f < FW; ++f) {
+        const int ch0 = (wm * FW + f) * 16 + lq * 4;
+        if (ch0 >= a.HP) continue;
+        float4 bt = make_float4(0.f, 0.f, 0.f, 0.f), bs = bt;
+        if (ch0 < a.H) { bt = *reinterpret_cast<const float4*>(bb + ch0); bs = *reinterpret_cast<const float4*>(bb + a.H + ch0); }
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          const int j = n * 16 + lrow;
+          const f32x4 t = acc[f][n], sg = acc[FW + f][n];
+          quad o;
+          if (ch0 < a.H) {
+            o[0] = O::cvt(fast_tanh(t[0] + bt.x) * fast_sigmoid(sg[0] + bs.x));
+            o[1] = O::cvt(fast_tanh(t[1] + bt.y) * fast_sigmoid(sg[1] + bs.y));
+            o[2] = O::cvt(fast_tanh(t[2] + bt.z) * fast_sigmoid(sg[2] + bs.z));
+            o[3] = O::cvt(fast_tanh(t[3] + bt.w) * fast_sigmoid(sg[3] + bs.w));
+          } else {
+            o[0] = o[1] = o[2] = o[3] = (T)0.f;
+          }
+          *reinterpret_cast<quad*>(acts + j * rowbytes + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
+        }
+      }
+    }
+    __syncthreads();                          // acts complete; every wave is done reading the x tile
+    {   // ---- GEMM2 (1x1): x += res, out += skip   (modules.py:104-112)
+      f32x4 acc[MF][NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* brs = a.b_rs[l];
+      if (!last) {
+        const frag* ap = static_cast<const frag*>(a.w_rs[l]) + ((size_t)wm * a.KS * MF) * 64 + lane;
+        gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+#pragma unroll
+        for (int f = 0; f < FW; ++f) {
+          const int ch0 = (wm * FW + f) * 16 + lq * 4;
+          if (ch0 >= a.H) continue;
+          const float4 b0 = *reinterpret_cast<const float4*>(brs + ch0);
+          const float4 b1 = *reinterpret_cast<const float4*>(brs + a.H + ch0);
+#pragma unroll
+          for (int n = 0; n < NF; ++n) {
+            const int q = w0 + n * 16 + lrow;
+            const bool in = q >= 0 && q < a.T;                  // the convs zero-pad x outside the utterance
+            xr[f][n][0] = in ? xr[f][n][0] + acc[f][n][0] + b0.x : 0.f;
+            xr[f][n][1] = in ? xr[f][n][1] + acc[f][n][1] + b0.y : 0.f;
+            xr[f][n][2] = in ? xr[f][n][2] + acc[f][n][2] + b0.z : 0.f;
+            xr[f][n][3] = in ? xr[f][n][3] + acc[f][n][3] + b0.w : 0.f;
+            if (n >= OLO && n < OLO + ON) {
+              outr[f][n - OLO][0] += acc[FW + f][n][0] + b1.x; outr[f][n - OLO][1] += acc[FW + f][n][1] + b1.y;
+              outr[f][n - OLO][2] += acc[FW + f][n][2] + b1.z; outr[f][n - OLO][3] += acc[FW + f][n][3] + b1.w;
+            }
+          }
+        }
+        put_x();                              // safe: all waves are past GEMM1 of this layer
+      } else {
+        f32x4 (&acl)[FW][NF] = reinterpret_cast<f32x4 (&)[FW][NF]>(acc);
+        const frag* ap = static_cast<const frag*>(a.w_rs[l]) + ((size_t)wm * a.KS * FW) * 64 + lane;
+        gemm_loop<T, FW, NF, QVC_PF_CONV>(acl, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+#pragma unroll
+        for (int f = 0; f < FW; ++f) {
+          const int ch0 = (wm * FW + f) * 16 + lq * 4;
+          if (ch0 >= a.H) continue;
+          const float4 b0 = *reinterpret_cast<const float4*>(brs + ch0);
+#pragma unroll
+          for (int n = 0; n < NF; ++n) {
+            if (n >= OLO && n < OLO + ON) {
+              outr[f][n - OLO][0] += acl[f][n][0] + b0.x; outr[f][n - OLO][1] += acl[f][n][1] + b0.y;
+              outr[f][n - OLO][2] += acl[f][n][2] + b0.z; outr[f][n - OLO][3] += acl[f][n][3] + b0.w;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                          // x tile updated / acts tile free for the next layer
+  }
+
+  // ---- store the skip sum of the output tile
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    const int ch0 = (wm * FW + f) * 16 + lq * 4;
+    if (ch0 >= a.H) continue;
+#pragma unroll
+    for (int n = OLO; n < OLO + ON; ++n) {
+      const int q = w0 + n * 16 + lrow;
+      if (q >= q0 && q < q0 + kWnOutFrames && q < a.T)
+        *reinterpret_cast<float4*>(a.out + (size_t)b * a.bs + (size_t)q * a.H + ch0) =
+            make_float4(outr[f][n - OLO][0], outr[f][n - OLO][1], outr[f][n - OLO][2], outr[f][n - OLO][3]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ launch-side tile selection
 struct TileChoice { int NF; int blocks; size_t lds; };
 
@@ -804,6 +976,37 @@ int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* strea
     case 34: return launch_wn_one<T, 3, 4>(a, batch, stream);
     case 42: return launch_wn_one<T, 4, 2>(a, batch, stream);
     case 44: return launch_wn_one<T, 4, 4>(a, batch, stream);
+    default: return QVC_ERR_BAD_CONFIG;
+  }
+}
+
+// ---- whole-stack WaveNet dispatch
+template <typename T, int FW, int NF>
+inline int launch_wn_stack_one(const WnStackArgs& a, int batch, hipStream_t stream) {
+  auto kern = wn_stack_kernel<T, FW, NF>;
+  const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return QVC_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, kWnOutFrames), (unsigned)batch), dim3(256), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream_v) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (!wn_stack_ok(din, a.layers)) return QVC_ERR_BAD_CONFIG;
+  const int nf = wn_stack_nf(a.taps, a.layers), fw = din.MF / 2;
+  switch (fw * 10 + nf) {
+    case 13: return launch_wn_stack_one<T, 1, 3>(a, batch, stream);
+    case 16: return launch_wn_stack_one<T, 1, 6>(a, batch, stream);
+    case 23: return launch_wn_stack_one<T, 2, 3>(a, batch, stream);
+    case 26: return launch_wn_stack_one<T, 2, 6>(a, batch, stream);
+    case 33: return launch_wn_stack_one<T, 3, 3>(a, batch, stream);
+    case 36: return launch_wn_stack_one<T, 3, 6>(a, batch, stream);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }

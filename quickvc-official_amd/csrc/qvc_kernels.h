@@ -65,6 +65,20 @@ struct WnArgs {
   int32_t taps = 1, KS = 1, nIt1 = 1, last = 0;
 };
 
+// A whole WaveNet stack (modules.py:69-114) in one launch: every workgroup carries a 32-frame output tile
+// plus (taps-1)/2 * layers halo frames per side through all layers (overlap-tiled: the halo is recomputed,
+// which is free because the layer is bound by weight delivery into the CU, not by the MFMA pipe).
+constexpr int kWnMaxLayers = 16;
+constexpr int kWnOutFrames = 32;
+struct WnStackArgs {
+  const float* x0 = nullptr;   // [B][T][H] stack input (pre conv output)
+  float* out = nullptr;        // [B][T][H] sum of the skip paths (the stack's output)
+  int64_t bs = 0; int32_t T = 0, H = 0, HP = 0;
+  const void* w_in[kWnMaxLayers] = {}; const void* w_rs[kWnMaxLayers] = {}; const float* b_rs[kWnMaxLayers] = {};
+  const float* bbias = nullptr; int64_t bbias_bs = 0;     // + l*2H per layer
+  int32_t layers = 0, taps = 1, KS = 1, nIt1 = 1;
+};
+
 struct GemvArgs {
   const float* w; const float* bias; const float* g; float* out;
   int32_t rows, gin, batch;
@@ -86,6 +100,8 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
+bool wn_stack_supported(const ConvDesc& din, int layers);
+int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dtype, void* stream);
 int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 int launch_gemv(const GemvArgs& a, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
@@ -93,6 +109,7 @@ int launch_tail(const TailArgs& a, void* stream);
 
 // Instantiation entry (one translation unit per operand dtype).
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
+template <typename T> int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream);
 template <typename T> int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream, int* nf_out);
 template <typename T> int launch_pair_typed(const ConvDesc& d1, const PairArgs& a, int batch, void* stream, int* nf_out);
 

@@ -11,6 +11,8 @@
 //                      int wn(const ConvDesc& in, const ConvDesc& rs, const WnArgs&, int batch, int dtype);
 //                      int gemv(const GemvArgs&); int sample(const SampleArgs&);
 //                      int tail(const TailArgs&); int zero(void* ptr, size_t bytes);
+//                      void fork(int n); void branch(int j); void branch_done(int j);
+//                      void wait_branch_done(int j); void join(int n);   (stream fork/join; no-ops on one stream)
 #pragma once
 #include "qvc_kernels.h"
 
@@ -60,6 +62,18 @@ struct Path {
   void wn(const WNPlan& wn, const float* bb, int64_t bb_bs) {
     const int H = P.cfg.hidden_channels;
     const int64_t bs = (int64_t)T * H;
+    if (wn_stack_ok(wn.in_conv[0], wn.layers) && be.use_wn_stack(B, T)) {
+      WnStackArgs a;
+      a.x0 = wsp<float>(W.xw); a.out = wsp<float>(W.oacc); a.bs = bs; a.T = T; a.H = H; a.HP = wn.in_conv[0].CinP;
+      for (int l = 0; l < wn.layers; ++l) {
+        a.w_in[l] = blob + wn.in_conv[l].w_off; a.w_rs[l] = blob + wn.rs_conv[l].w_off;
+        a.b_rs[l] = reinterpret_cast<const float*>(blob + wn.rs_conv[l].b_off);
+      }
+      a.bbias = bb; a.bbias_bs = bb_bs;
+      a.layers = wn.layers; a.taps = wn.in_conv[0].taps; a.KS = wn.in_conv[0].KS(); a.nIt1 = wn.in_conv[0].nIt();
+      if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype());
+      return;
+    }
     zero(W.oacc, (int64_t)B * bs * 4);
     for (int l = 0; l < wn.layers; ++l) {
       const ConvDesc& din = wn.in_conv[l];
@@ -154,17 +168,24 @@ struct Path {
         a.y16 = wsp<void>(W.u[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;   // raw, operand type
         conv(st.up, a);
       }
-      for (int j = 0; j < c.n_resblocks; ++j) {
-        const void* src = wsp<void>(W.u[i]);
-        for (int q = 0; q < 3; ++q) {
+      // The ResBlocks of a stage are independent until their mean: branch j runs on stream j (when
+      // the backend has auxiliary streams; otherwise the same order on one stream).  The last pair of
+      // each branch accumulates into the MRF mean, so those launches are chained j-1 -> j.
+      const int NB = c.n_resblocks;
+      be.fork(NB);                                   // branches wait for everything enqueued so far
+      std::vector<const void*> src((size_t)NB, wsp<void>(W.u[i]));
+      for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < NB; ++j) {
+          be.branch(j);
           const ConvDesc& d1 = st.c1[(size_t)j * 3 + q];
           const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
-          void* dst = q == 0 ? wsp<void>(W.ra[i]) : wsp<void>(W.rb[i]);
-          const bool last = q == 2;          // the last pair of each ResBlock goes straight into the MRF mean
-          const float scale = 1.f / (float)c.n_resblocks;
+          void* dst = q == 0 ? wsp<void>(W.ra[i][(size_t)j]) : wsp<void>(W.rb[i][(size_t)j]);
+          const bool last = q == 2;
+          const float scale = 1.f / (float)NB;
+          if (last && j > 0) be.wait_branch_done(j - 1);       // accumulate after the previous branch's mean update
           if (pair_supported(d1, d2)) {
             PairArgs pa;
-            pa.x = src; pa.bs = bs; pa.T = t_out; pa.C = ch; pa.CP = d1.CinP;
+            pa.x = src[(size_t)j]; pa.bs = bs; pa.T = t_out; pa.C = ch; pa.CP = d1.CinP;
             pa.w1 = blob + d1.w_off; pa.b1 = reinterpret_cast<const float*>(blob + d1.b_off);
             pa.w2 = blob + d2.w_off; pa.b2 = reinterpret_cast<const float*>(blob + d2.b_off);
             pa.k = d1.taps; pa.dil = d1.dil; pa.KS = d1.KS(); pa.nIt = d1.nIt(); pa.slope = 0.1f;
@@ -172,26 +193,28 @@ struct Path {
             else pa.y = dst;
             if (status == QVC_OK) status = be.pair(d1, d2, pa, B, dtype());
           } else {
+            void* xt = wsp<char>(W.xt[i]) + (size_t)j * (size_t)B * (size_t)bs * 2;
             {   // lrelu -> dilated conv -> lrelu (stored already activated)
               ConvArgs a = args(d1);
-              a.x = src; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out; a.slope_in = 0.1f;
+              a.x = src[(size_t)j]; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out; a.slope_in = 0.1f;
               a.Nq = t_out; a.T_out = t_out;
-              a.y16 = wsp<void>(W.xt[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 0.1f;
+              a.y16 = xt; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 0.1f;
               conv(d1, a);
             }
             {   // conv -> + x
               ConvArgs a = args(d2);
-              a.x = wsp<void>(W.xt[i]); a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
+              a.x = xt; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
               a.Nq = t_out; a.T_out = t_out;
-              a.res16 = src; a.res_bs = bs; a.res_ts = ch;
+              a.res16 = src[(size_t)j]; a.res_bs = bs; a.res_ts = ch;
               if (last) { a.y32 = wsp<float>(W.m[i]); a.y32_bs = bs; a.y32_ts = ch; a.y_scale = scale; a.y_accum = j > 0 ? 1 : 0; }
               else { a.y16 = dst; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f; }
               conv(d2, a);
             }
           }
-          src = dst;
+          if (last) be.branch_done(j);
+          src[(size_t)j] = dst;
         }
-      }
+      be.join(NB);                                   // main stream continues after the last branch's mean update
       t_in = t_out; ch_in = ch;
     }
     {   // lrelu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post(k7)

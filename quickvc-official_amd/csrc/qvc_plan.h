@@ -93,6 +93,16 @@ inline bool pair_supported(const ConvDesc& d1, const ConvDesc& d2) {
   return lds <= 160 * 1024;
 }
 
+// Whole-stack WaveNet kernel: window = 32 output frames + halo, built for 3 or 6 column fragments.
+inline int wn_stack_nf(int taps, int layers) { return ceil_div(32 + (taps - 1) * layers, 16); }
+inline bool wn_stack_ok(const ConvDesc& din, int layers) {
+  const int nf = wn_stack_nf(din.taps, layers);
+  const int fw = din.MF / 2;
+  const int halo = (din.taps - 1) / 2 * layers;                  // output frames = window columns [halo, halo+32)
+  const bool cols_ok = nf == 3 || (nf == 6 && halo >= 16 && halo + 32 <= 64);   // fragments 1..3 hold the skip sum when nf == 6
+  return din.gau && din.WM == 4 && din.nchunk == 1 && layers <= 16 && (nf == 3 || nf == 6) && cols_ok && fw >= 1 && fw <= 3;
+}
+
 struct WNPlan {
   int32_t layers = 0;
   std::vector<ConvDesc> in_conv;   // k-tap h -> 2h, GAU row order; bias lives in the cond/bias table
@@ -141,7 +151,7 @@ inline int validate(const qvc_config& c) {
   auto bad = [](bool cond) { return cond; };
   if (bad(c.unit_channels <= 0 || c.inter_channels <= 0 || c.hidden_channels <= 0 || c.gin_channels <= 0)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.inter_channels % 8 || c.hidden_channels % 8 || c.unit_channels % 8)) return QVC_ERR_BAD_CONFIG;
-  if (bad(c.hidden_channels > 256)) return QVC_ERR_BAD_CONFIG;   // one workgroup owns all WN channels (4 waves x 4 x 16)
+  if (bad(c.hidden_channels > 256 || c.gin_channels % 4 || c.gin_channels > 512)) return QVC_ERR_BAD_CONFIG;   // one workgroup owns all WN channels (4 waves x 4 x 16)
   if (bad(c.wn_kernel_size < 1 || c.wn_kernel_size % 2 == 0 || c.wn_kernel_size > 15)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.enc_layers < 1 || c.enc_layers > 64 || c.flow_layers < 1 || c.flow_layers > 64)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.n_flows < 1 || c.n_flows > 16 || c.n_flows % 2)) return QVC_ERR_BAD_CONFIG;   // flips must cancel
@@ -269,7 +279,8 @@ struct Workspace {
   int64_t stats = 0;     // fp32 [B][T][2C]             enc_p.proj output
   int64_t z = 0;         // fp32 [B][T][C]              latent (flow state)
   int64_t c0 = 0;        // op   [B][T][init_ch]        lrelu(conv_pre + cond)
-  std::vector<int64_t> u, ra, rb, xt, m;   // per stage: up output, ResBlock stream ping/pong, conv1 output (op type); MRF mean (fp32)
+  std::vector<int64_t> u, xt, m;           // per stage: up output, conv1 output (op type, unfused fallback); MRF mean (fp32)
+  std::vector<std::vector<int64_t>> ra, rb;   // per stage, per ResBlock: stream ping/pong (op type) -- ResBlocks may run concurrently
   int64_t post = 0;      // fp32 [B][F][post_channels]
   int64_t bytes = 0;
 };
@@ -293,9 +304,9 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
     t *= P.stages[i].rate;
     int64_t n = (int64_t)B * t * P.stages[i].ch;
     W.u.push_back(take(n * 2));
-    W.ra.push_back(take(n * 2));
-    W.rb.push_back(take(n * 2));
-    W.xt.push_back(take(n * 2));
+    W.ra.emplace_back(); W.rb.emplace_back();
+    for (int j = 0; j < c.n_resblocks; ++j) { W.ra.back().push_back(take(n * 2)); W.rb.back().push_back(take(n * 2)); }
+    W.xt.push_back(take(n * 2 * c.n_resblocks));
     W.m.push_back(take(n * 4));
   }
   W.post = take((int64_t)B * (t + 1) * P.post_channels * 4);

@@ -12,27 +12,42 @@
 namespace qvc {
 
 // ------------------------------------------------------------------ cond GEMV
-// out[b][row] = bias[row] + sum_k w[row][k] * g[b][k].  One wave per row; the row (<= a few KB)
-// is read once, coalesced, and reused for every utterance of the batch.
+// out[b][row] = bias[row] + sum_k w[row][k] * g[b][k].  A workgroup owns kGR rows x the whole batch:
+// the g vectors are staged into LDS once per workgroup ([k][b], so the 32 utterances of one k sit in
+// 32 different banks), each thread owns one (row, utterance) pair and walks k with the weight row read
+// as wave-wide broadcasts.  ~0.1 GFLOP in total: latency-sized, it only has to stay out of the way.
+constexpr int kGR = 8, kGB = 32;
 __global__ __launch_bounds__(256) void cond_gemv_kernel(const GemvArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
-  const float* wr = a.w + (size_t)row * a.gin;
-  const float bias = a.bias[row];
-  for (int b = 0; b < a.batch; ++b) {
-    const float* gb = a.g + (size_t)b * a.gin;
-    float s = 0.f;
-    for (int k = lane; k < a.gin; k += 64) s = fmaf(wr[k], gb[k], s);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) a.out[(size_t)b * a.rows + row] = s + bias;
+  extern __shared__ float s_g[];                        // [gin][kGB]
+  const int tid = threadIdx.x;
+  const int r = tid >> 5, bl = tid & 31;
+  const int row = blockIdx.x * kGR + r;
+  for (int b0 = 0; b0 < a.batch; b0 += kGB) {
+    __syncthreads();
+    for (int i = tid; i < a.gin * kGB; i += 256) {
+      const int k = i >> 5, b = i & 31;
+      s_g[i] = (b0 + b < a.batch) ? a.g[(size_t)(b0 + b) * a.gin + k] : 0.f;
+    }
+    __syncthreads();
+    if (row < a.rows && b0 + bl < a.batch) {
+      const float* wr = a.w + (size_t)row * a.gin;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int k = 0;
+      for (; k + 4 <= a.gin; k += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+        s0 = fmaf(w4.x, s_g[(k + 0) * kGB + bl], s0); s1 = fmaf(w4.y, s_g[(k + 1) * kGB + bl], s1);
+        s2 = fmaf(w4.z, s_g[(k + 2) * kGB + bl], s2); s3 = fmaf(w4.w, s_g[(k + 3) * kGB + bl], s3);
+      }
+      for (; k < a.gin; ++k) s0 = fmaf(wr[k], s_g[k * kGB + bl], s0);
+      a.out[(size_t)(b0 + bl) * a.rows + row] = (s0 + s1) + (s2 + s3) + a.bias[row];
+    }
   }
 }
 
 int launch_gemv(const GemvArgs& a, void* stream) {
   if (a.rows <= 0) return QVC_OK;
-  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, 4)), dim3(256), 0,
+  if (a.gin % 4 || (size_t)a.gin * kGB * 4 > 64 * 1024) return QVC_ERR_BAD_CONFIG;
+  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, kGR)), dim3(256), (size_t)a.gin * kGB * 4,
                      static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
@@ -104,11 +119,14 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
     float re[kBins], im[kBins];
 #pragma unroll
     for (int q = 0; q < kBins; ++q) {
-      const float mag = expf(sp[q]);
-      const float ph = kPi * sinf(sp[kBins + q]);
-      float sn, cs;
-      sincosf(ph, &sn, &cs);
-      re[q] = mag * cs; im[q] = mag * sn;
+      // hardware transcendentals: v_exp_f32 (1 ulp), v_sin/v_cos_f32 take revolutions.  The phase
+      // pi*sin(p) lies in [-pi, pi] = [-0.5, 0.5] revolutions, the sweet spot of v_sin/v_cos (abs err
+      // ~1e-6); p itself is reduced with an exact fract() first.
+      const float mag = __builtin_amdgcn_exp2f(1.4426950408889634f * sp[q]);
+      const float pr = sp[kBins + q] * 0.15915494309189535f;              // p / 2pi
+      const float sp_ = __builtin_amdgcn_sinf(pr - floorf(pr));            // sin(p)
+      const float rev = 0.5f * sp_;                                        // pi*sin(p) / 2pi
+      re[q] = mag * __builtin_amdgcn_cosf(rev); im[q] = mag * __builtin_amdgcn_sinf(rev);
     }
     // twiddles cos/sin(2*pi*j/16), j = 0..15, as compile-time constants after unrolling
     constexpr float C16[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
@@ -224,6 +242,14 @@ int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, vo
   a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout;
   if (dtype == QVC_F16) return launch_conv_typed<_Float16>(d, a, batch, epi, stream, nf_out);
   if (dtype == QVC_BF16) return launch_conv_typed<__bf16>(d, a, batch, epi, stream, nf_out);
+  return QVC_ERR_BAD_ARG;
+}
+
+bool wn_stack_supported(const ConvDesc& din, int layers) { return wn_stack_ok(din, layers); }
+
+int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dtype, void* stream) {
+  if (dtype == QVC_F16) return launch_wn_stack_typed<_Float16>(din, a, batch, stream);
+  if (dtype == QVC_BF16) return launch_wn_stack_typed<__bf16>(din, a, batch, stream);
   return QVC_ERR_BAD_ARG;
 }
 

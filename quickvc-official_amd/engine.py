@@ -22,7 +22,7 @@ def _aligned_empty(nbytes: int, device) -> torch.Tensor:
 
 
 class QvcEngine:
-    def __init__(self, model_config: dict, state_dict: Dict[str, torch.Tensor], device):
+    def __init__(self, model_config: dict, state_dict: Dict[str, torch.Tensor], device, parallel_branches: bool = True):
         self.lib = L.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -34,12 +34,25 @@ class QvcEngine:
         host_blob = L.pack_weights(self.lib, self.cfg, state_dict)
         self.blob = _aligned_empty(host_blob.numel(), self.device)
         self.blob.copy_(host_blob)
+        # fork/join resources for the parallel ResBlock branches (two aux streams + events)
+        self._aux = ctypes.c_void_p(None)
+        if parallel_branches:
+            with torch.cuda.device(self.device):
+                L.check(self.lib, self.lib.qvc_aux_create(ctypes.byref(self._aux)), "qvc_aux_create")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key = None
         n = model_config["gen_istft_hop_size"] * model_config["subbands"]
         for u in model_config["upsample_rates"]:
             n *= u
         self.samples_per_frame = n
+
+    def __del__(self):
+        try:
+            if getattr(self, "_aux", None) is not None and self._aux.value:
+                self.lib.qvc_aux_destroy(self._aux)
+                self._aux = ctypes.c_void_p(None)
+        except Exception:
+            pass
 
     # weights can also arrive from another rank (one broadcast at start-up)
     def load_blob_(self, blob: torch.Tensor) -> None:
@@ -73,8 +86,9 @@ class QvcEngine:
             out = torch.empty(B, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, T)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        st = self.lib.qvc_infer_batch(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
-                                      noise.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), ws.numel(), stream)
+        st = self.lib.qvc_infer_batch_ex(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
+                                         noise.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), ws.numel(), stream,
+                                         self._aux)
         L.check(self.lib, st, "qvc_infer_batch")
         return out
 

@@ -66,6 +66,12 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_workspace_bytes.argtypes = [cfgp, I, I]
         lib.qvc_infer_batch.restype = ctypes.c_int
         lib.qvc_infer_batch.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
+        lib.qvc_aux_create.restype = ctypes.c_int
+        lib.qvc_aux_create.argtypes = [P(V)]
+        lib.qvc_aux_destroy.restype = ctypes.c_int
+        lib.qvc_aux_destroy.argtypes = [V]
+        lib.qvc_infer_batch_ex.restype = ctypes.c_int
+        lib.qvc_infer_batch_ex.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V, V]
         lib.qvc_infer_batch_timed.restype = ctypes.c_int
         lib.qvc_infer_batch_timed.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V, P(QvcLaunchRecord), I, P(I)]
         lib.qvc_enc_p.restype = ctypes.c_int

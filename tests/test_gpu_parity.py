@@ -190,6 +190,25 @@ def test_infer_api_matches_reference_semantics(lib, dev):
     assert snr_db(2.0 * spk["infer_o"], o2.cpu().numpy()) >= 45.0
 
 
+def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev):
+    """B=32, T=250 takes the whole-stack WaveNet kernel (16 / 4 layers per launch, overlap-tiled); a small
+    batch of the same utterances takes one launch per layer.  Same K order per frame -> identical results."""
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    unit, g, noise = make_synthetic_inputs(32, 250, 256, 192, 256, seed0=300)
+    z_big = eng.enc_p(unit, noise)
+    _, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
+    assert sum(r["name"].startswith("wn_stack<") for r in recs) == 5
+    z_small = eng.enc_p(unit[:2], noise[:2])
+    torch.cuda.synchronize()
+    assert snr_db(z_small.cpu(), z_big[:2].cpu()) >= 100.0
+    zf_big = eng.flow_reverse(z_big, g)
+    zf_small = eng.flow_reverse(z_big[:2], g[:2])
+    assert snr_db(zf_small.cpu(), zf_big[:2].cpu()) >= 100.0
+
+
 def test_hipgraph_capture_replays_identically(lib, dev):
     entry, _ = load_case("mini_t37")
     _m, sd, unit, g, noise = regenerate(entry)
@@ -222,6 +241,7 @@ def test_timed_variant_reports_every_launch(lib, dev):
     # enc: pre + proj; flow: 4 x (pre + post); dec: conv_pre + 2 ups + conv_post; 16 + 4x4 fused WN layers;
     # 2 x 9 fused ResBlock pairs
     assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2 + 1
+    # mini B=2, T=12: too few tiles for the whole-stack kernel -> one launch per WaveNet layer
     assert sum(n.startswith("wn_layer<") for n in names) == 32
     assert sum(n.startswith("rbpair<") for n in names) == 18
     assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0
