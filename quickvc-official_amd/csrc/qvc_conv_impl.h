@@ -83,7 +83,7 @@ __device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, f
 // wave = PF * MF KiB: the weight stream of a layer is cold (touched once per step), so small-tile kernels
 // (WaveNet layer) need a deep ring to cover the L2/MALL round trip; big-tile kernels are MFMA-paced.
 #ifndef QVC_PF_CONV
-#define QVC_PF_CONV 2
+#define QVC_PF_CONV 3
 #endif
 // k-step rotation of a workgroup (see gemm_loop); QVC_NO_ROT=1 disables it for A/B measurements
 // (measured: no effect on gfx950 -- the L2 is not the limiter -- so it is off; QVC_ROTATE=1 enables it)
@@ -99,7 +99,7 @@ __device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, f
 #define QVC_ABL(bit) 0
 #endif
 #ifndef QVC_PF_WN
-#define QVC_PF_WN 4
+#define QVC_PF_WN 3
 #endif
 
 // The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
@@ -113,11 +113,21 @@ template <typename T, int MF, int NF, int kPF>
 __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
                                           const char* tile, int rowbytes, Swz sm, int colrow, int lq, int rot) {
   // `rot`: optional rotated start of the walk over the k-steps (QVC_ROTATE, off by default)
+  //
+  // Software pipeline (all register indices static after unrolling RING = kPF+1 steps, RING even):
+  //   A fragments: global -> register ring, kPF k-steps ahead (plain loads, hipcc counts them);
+  //   B fragments: LDS -> a double buffer, ONE k-step ahead.  Left to itself hipcc keeps two
+  //   B buffers and alternates ds_read / wait / MF MFMAs, which exposes the LDS latency on every
+  //   fragment (seen in the ISA: ~55 % MFMA issue in the loop).  Here all NF reads of step i+1 are
+  //   in flight while the MF*NF MFMAs of step i run; sched_barrier pins that order.
   using O = Op<T>;
   using frag = typename O::frag;
   constexpr int RING = kPF + 1;
+  static_assert(RING % 2 == 0, "the B double buffer needs an even ring");
   frag ar[RING][MF];
-  int pf = rot;                                                 // physical k-step of the next prefetch
+  frag bf[2][NF];
+  const int nstride = 16 * rowbytes;
+  int pf = rot;                                                 // physical k-step of the next A prefetch
 #pragma unroll
   for (int u = 0; u < kPF; ++u)
     if (u < nIt) {
@@ -125,8 +135,16 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
       for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)pf * MF + m) * 64];
       if (++pf == nIt) pf = 0;
     }
-  const int nstride = 16 * rowbytes;
-  int tap = rot / KS, ks = rot - tap * KS;
+  int tap = rot / KS, ks = rot - tap * KS;                      // k-step whose B fragments are read next
+  auto read_b = [&](frag (&dst)[NF]) {
+    const int row0 = tap * dil + colrow;
+    const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
+#pragma unroll
+    for (int n = 0; n < NF; ++n) dst[n] = *reinterpret_cast<const frag*>(bp + n * nstride);
+    if (++ks == KS) { ks = 0; ++tap; }
+    if (tap * KS + ks == nIt) { tap = 0; ks = 0; }
+  };
+  if (nIt > 0) read_b(bf[0]);
   for (int it0 = 0; it0 < nIt; it0 += RING) {
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
@@ -137,17 +155,13 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
           for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pf * MF + m) * 64];
           if (++pf == nIt) pf = 0;
         }
-        const int row0 = tap * dil + colrow;
-        const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
-        frag bf[NF];
-#pragma unroll
-        for (int n = 0; n < NF; ++n) bf[n] = *reinterpret_cast<const frag*>(bp + n * nstride);
+        if (it + 1 < nIt) read_b(bf[(u + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);                      // loads stay above this step's MFMAs
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
-          for (int m = 0; m < MF; ++m) acc[m][n] = O::mfma(ar[u][m], bf[n], acc[m][n]);
-        if (++ks == KS) { ks = 0; ++tap; }
-        if (tap * KS + ks == nIt) { tap = 0; ks = 0; }
+          for (int m = 0; m < MF; ++m) acc[m][n] = O::mfma(ar[u][m], bf[u & 1][n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -818,9 +832,14 @@ inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* n
     if (lds > 160 * 1024) continue;
     const int tiles = ceil_div(Nq, NT);
     const long blocks = (long)tiles * batch * d.nchunk;
-    const long per_cu = (blocks + 255) / 256;
+    // workgroups that can share a CU (LDS, and the ~512 registers/lane of a SIMD): with >= 2 the
+    // staging / epilogue of one overlaps the MFMA phase of another
+    const int regs = d.MF * NF * 4 + 16 * d.MF + 8 * NF + 40;
+    const int bpc = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(3, (160 * 1024) / lds), (size_t)(512 / regs)));
+    const long rounds = (blocks + 256L * bpc - 1) / (256L * bpc);
     // work per block ~ frames computed + a fixed overhead (staging, launch, epilogue), in frame units
-    const double cost = (double)per_cu * (NT + 0.35 * halo + 24.0);
+    const double work = NT + 0.35 * halo + 24.0;
+    const double cost = (double)rounds * bpc * work * (bpc == 1 ? 1.3 : 1.0);
     if (cost < best_cost) { best_cost = cost; best = TileChoice{NF, (int)blocks, lds}; }
   }
   return best;
