@@ -44,7 +44,7 @@ def main() -> None:
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-branches", action="store_true", help="run the ResBlocks of a stage one after the other")
+    ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches")
     args = ap.parse_args()
 
     import torch
@@ -69,7 +69,7 @@ def main() -> None:
     model = q.SynthesizerTrn(641, 32, **cfg, operand_dtype=args.dtype)
     # rank 0 owns the checkpoint; everybody else receives the packed blob in ONE broadcast
     sd = make_synthetic_state_dict(model, 1234)
-    engine = QvcEngine(model.model_config, sd, device, parallel_branches=not args.no_branches)   # every rank packs; then overwritten:
+    engine = QvcEngine(model.model_config, sd, device, parallel_branches=args.branches)   # every rank packs; then overwritten:
     if world > 1:
         qd.broadcast_blob(engine.blob, src=0)                 # RCCL over xGMI, once
     B = args.batch
@@ -122,7 +122,7 @@ def main() -> None:
         "config": {"workload": "batch=32 offline VC, 5 s 16 kHz utterances, 1xMI355X per rank (BASELINE.json configs[2])",
                    "batch_per_gpu": B, "frames": FRAMES, "samples_per_utterance": FRAMES * engine.samples_per_frame,
                    "operands": f"{args.dtype} MFMA operands, fp32 accumulate", "hipgraph": graph is not None,
-                   "parallel_resblock_branches": not args.no_branches,
+                   "parallel_resblock_branches": args.branches,
                    "parallelism": f"utterance-sharded x{world}, no per-step collective"},
         "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
     }
