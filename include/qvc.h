@@ -90,7 +90,7 @@ typedef struct qvc_config {
   int32_t decoder;                  /* QVC_DEC_*                                         */
   int32_t fir_taps;                 /* 63: multistream_conv_post / PQMF taps+1           */
   int32_t operand_dtype;            /* QVC_BF16 / QVC_F16                                */
-  int32_t precise_post;             /* 1: conv_post with split (hi+lo) operands          */
+  int32_t reserved0;                /* must be 0                                          */
 } qvc_config;
 
 /* One named fp32 tensor of the reference checkpoint's state_dict (utils.py:183-193). */

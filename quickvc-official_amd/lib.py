@@ -31,7 +31,7 @@ class QvcConfig(ctypes.Structure):
         ("resblock_kernel_sizes", ctypes.c_int32 * QVC_MAX_RESBLOCKS),
         ("resblock_dilations", (ctypes.c_int32 * 3) * QVC_MAX_RESBLOCKS),
         ("n_fft", ctypes.c_int32), ("hop", ctypes.c_int32), ("subbands", ctypes.c_int32), ("decoder", ctypes.c_int32),
-        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("precise_post", ctypes.c_int32),
+        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -144,7 +144,7 @@ def make_config(mc: dict) -> QvcConfig:
     if dt not in DTYPES:
         raise QvcError(f"operand_dtype must be one of {sorted(DTYPES)}")
     c.operand_dtype = DTYPES[dt]
-    c.precise_post = 0
+    c.reserved0 = 0
     return c
 
 

@@ -1,0 +1,81 @@
+"""Exact chunked conversion of many concurrent streams (BASELINE.json configs[4]).
+
+The reference processes a whole utterance in one shot (no chunking, no streaming).  Every
+op on the path is a convolution with a bounded receptive field -- measured on the oracle: an input
+frame influences output frames within +-84 frames (enc_p WN 32, flow 32, decoder ~20) -- and the speaker
+embedding g is global, so a window of ``hop + 2*context`` frames reproduces its central ``hop`` frames
+exactly when ``context >= 84``.  Windows are clamped to the utterance, so the first / last window touch
+the true sequence edges and stay exact there too (the convs zero-pad activations at the *sequence*
+edges at every layer, which a zero-padded window could not reproduce).
+
+All windows have ONE shape, (streams, 256, hop + 2*context), so the launch sequence is captured once
+in a hipGraph and replayed per chunk.  Latency of a streamed chunk = ``context`` frames of look-ahead.
+"""
+from __future__ import annotations
+
+from typing import Iterator, Optional, Tuple
+
+import torch
+
+RECEPTIVE_FRAMES = 84      # measured (tests/test_gpu_parity.py::test_chunked_streaming_is_exact re-checks it)
+
+
+class ChunkedConverter:
+    """Fixed-shape, graph-replayed windowed conversion for ``streams`` concurrent utterances."""
+
+    def __init__(self, model, streams: int, hop_frames: int = 320, context: int = 88, use_graph: bool = True):
+        if context < RECEPTIVE_FRAMES:
+            raise ValueError(f"context {context} < receptive field {RECEPTIVE_FRAMES}: chunks would not be exact")
+        self.model, self.streams, self.hop, self.context = model, streams, hop_frames, context
+        self.window = hop_frames + 2 * context
+        self.engine = model.engine()
+        dev = self.engine.device
+        mc = model.model_config
+        self.spf = model.samples_per_frame
+        self._unit = torch.zeros(streams, mc.get("unit_channels", 256), self.window, device=dev)
+        self._noise = torch.zeros(streams, mc["inter_channels"], self.window, device=dev)
+        self._g = torch.zeros(streams, mc["gin_channels"], device=dev)
+        self._out = torch.zeros(streams, 1, self.window * self.spf, device=dev)
+        self._graph = None
+        self._stream = torch.cuda.Stream(dev)
+        if use_graph:
+            with torch.cuda.stream(self._stream):
+                self.engine.infer_batch(self._unit, self._g, self._noise, self._out)      # warm-up (workspace, code objects)
+                self._stream.synchronize()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph, stream=self._stream):
+                    self.engine.infer_batch(self._unit, self._g, self._noise, self._out)
+
+    def windows(self, total_frames: int) -> Iterator[Tuple[int, int, int]]:
+        """(window_start, chunk_start, chunk_len) for every hop of an utterance of ``total_frames``."""
+        if total_frames < self.window:
+            raise ValueError(f"utterance of {total_frames} frames is shorter than one window ({self.window})")
+        for t0 in range(0, total_frames, self.hop):
+            n = min(self.hop, total_frames - t0)
+            a = min(max(t0 - self.context, 0), total_frames - self.window)
+            yield a, t0, n
+
+    @torch.no_grad()
+    def convert(self, unit: torch.Tensor, g: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """unit (S,256,T), g (S,gin), noise (S,inter,T) -> (S,1,T*samples_per_frame); == infer_batch on the whole thing."""
+        S, _, T = unit.shape
+        if S != self.streams:
+            raise ValueError(f"built for {self.streams} streams, got {S}")
+        dev = self.engine.device
+        if noise is None:
+            noise = torch.randn(S, self.model.model_config["inter_channels"], T, device=dev)
+        unit, noise = unit.to(dev, torch.float32), noise.to(dev, torch.float32)
+        out = torch.empty(S, 1, T * self.spf, device=dev)
+        with torch.cuda.stream(self._stream):
+            self._g.copy_(g.reshape(S, -1))
+            for a, t0, n in self.windows(T):
+                self._unit.copy_(unit[:, :, a:a + self.window])
+                self._noise.copy_(noise[:, :, a:a + self.window])
+                if self._graph is not None:
+                    self._graph.replay()
+                else:
+                    self.engine.infer_batch(self._unit, self._g, self._noise, self._out)
+                lo = (t0 - a) * self.spf
+                out[:, :, t0 * self.spf:(t0 + n) * self.spf].copy_(self._out[:, :, lo:lo + n * self.spf])
+            self._stream.synchronize()
+        return out

@@ -245,3 +245,26 @@ def test_timed_variant_reports_every_launch(lib, dev):
     assert sum(n.startswith("wn_layer<") for n in names) == 32
     assert sum(n.startswith("rbpair<") for n in names) == 18
     assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0
+
+
+def test_chunked_streaming_is_exact(lib, dev):
+    """BASELINE configs[4]: fixed-shape windows (hop + 2*88 frames of context), graph-replayed, several
+    concurrent streams.  Property: the concatenated chunks equal the whole-utterance conversion."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd.streaming import ChunkedConverter
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    model, sd, _u, _g, _n = regenerate(entry)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    S, T, hop = 3, 700, 160
+    unit, g, noise = make_synthetic_inputs(S, T, 256, 192, 256, seed0=40)
+    whole = model.infer_batch(unit.cuda(), g.cuda(), noise.cuda())
+    conv = ChunkedConverter(model, streams=S, hop_frames=hop, context=88, use_graph=True)
+    assert [w[0] for w in conv.windows(T)] == [0, 72, 232, 364, 364]          # clamped at both sequence edges
+    chunked = conv.convert(unit, g, noise)
+    torch.cuda.synchronize()
+    assert chunked.shape == whole.shape == (S, 1, 320 * T)
+    assert snr_db(whole.cpu(), chunked.cpu()) >= 90.0
+    with pytest.raises(ValueError):
+        ChunkedConverter(model, streams=S, hop_frames=hop, context=40)
