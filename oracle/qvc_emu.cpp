@@ -225,19 +225,21 @@ struct EmuBackend {
     return QVC_OK;
   }
   bool use_wn_stack(int, int) const { return true; }
+  int wn_stack_chunk(int layers) const { return layers % 4 == 0 ? 4 : layers; }
   // whole stack = the layers one after the other (x ping-pong in temporaries)
   int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& s, int B, int dtype) {
     std::vector<float> xa(s.x0, s.x0 + (size_t)B * s.bs), xb((size_t)B * s.bs, 0.f);
-    std::memset(s.out, 0, (size_t)B * s.bs * 4);
+    if (!s.accum) std::memset(s.out, 0, (size_t)B * s.bs * 4);
     for (int l = 0; l < s.layers; ++l) {
       WnArgs a;
       a.x_in = (l % 2 ? xb : xa).data(); a.x_out = (l % 2 ? xa : xb).data(); a.oacc = s.out;
       a.bs = s.bs; a.T = s.T; a.H = s.H; a.HP = s.HP;
       a.w_in = s.w_in[l]; a.w_rs = s.w_rs[l]; a.b_rs = s.b_rs[l];
       a.bbias = s.bbias + (size_t)l * 2 * s.H; a.bbias_bs = s.bbias_bs;
-      a.taps = s.taps; a.KS = s.KS; a.nIt1 = s.nIt1; a.last = l == s.layers - 1;
+      a.taps = s.taps; a.KS = s.KS; a.nIt1 = s.nIt1; a.last = s.final_layer && l == s.layers - 1;
       wn(din, a.last ? drs_last : drs, a, B, dtype);
     }
+    if (s.x_out) std::memcpy(s.x_out, (s.layers % 2 ? xb : xa).data(), (size_t)B * s.bs * 4);
     return QVC_OK;
   }
   // fused pair = the two convs back to back with the intermediate rounded to the operand type

@@ -5,6 +5,7 @@
 // call can be captured into a hipGraph by the caller.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -22,6 +23,13 @@ struct qvc_aux {
 
 namespace {
 using namespace qvc;
+
+// Layers per whole-stack WaveNet launch (QVC_WN_CHUNK overrides it for tuning runs).
+inline int wn_chunk(int layers) {
+  static const int env = [] { const char* e = std::getenv("QVC_WN_CHUNK"); return e ? std::atoi(e) : 0; }();
+  if (env > 0) return env <= layers ? env : layers;
+  return layers % 4 == 0 ? 4 : layers;
+}
 
 // Stream fork/join for the parallel ResBlock branches (branch 0 = the caller's stream).
 struct Branches {
@@ -62,6 +70,7 @@ struct HipBackend {
   int wn(const ConvDesc& din, const ConvDesc&, const WnArgs& a, int batch, int dtype) { return launch_wn(din, a, batch, dtype, stream); }
   // the stack kernel trades 3x recomputed halo for one launch: right when its grid fills the machine
   bool use_wn_stack(int batch, int frames) const { return (long)batch * ceil_div(frames, kWnOutFrames) >= 128; }
+  int wn_stack_chunk(int layers) const { return wn_chunk(layers); }
   int wn_stack(const ConvDesc& din, const ConvDesc&, const ConvDesc&, const WnStackArgs& a, int batch, int dtype) { return launch_wn_stack(din, a, batch, dtype, stream); }
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
@@ -129,6 +138,7 @@ struct TimedBackend {
     return st;
   }
   bool use_wn_stack(int batch, int frames) const { return (long)batch * ceil_div(frames, kWnOutFrames) >= 128; }
+  int wn_stack_chunk(int layers) const { return wn_chunk(layers); }
   int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& a, int batch, int dtype) {
     if (ev.empty()) mark();
     int st = launch_wn_stack(din, a, batch, dtype, stream);
@@ -136,7 +146,7 @@ struct TimedBackend {
     char name[48];
     std::snprintf(name, sizeof(name), "wn_stack<%s,FW%d,L%d>", dtype == QVC_F16 ? "f16" : "bf16", din.MF / 2, a.layers);
     const double cols = (double)batch * a.T;
-    const double fl = 2.0 * cols * a.H * (a.layers * 2.0 * a.H * a.taps + (a.layers - 1) * (double)drs.M + (double)drs_last.M);
+    const double fl = 2.0 * cols * a.H * (a.layers * 2.0 * a.H * a.taps + (a.layers - (a.final_layer ? 1 : 0)) * (double)drs.M + (a.final_layer ? (double)drs_last.M : 0.0));
     note(name, fl, cols * a.H * 8 + a.layers * ((double)din.w_bytes() + (double)drs.w_bytes()));
     return st;
   }

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
   const Swz sm = swz_mode(cpr);
   const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
 
+
   if (!QVC_ABL(0)) {   // ---- stage lrelu(x)
     const int t_base = q0 - h2 - h1;
     const int total = Rx * cpr;
@@ -691,7 +692,12 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ch0 < a.H && q >= 0 && q < a.T) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
       xr[f][n] = f32x4{v.x, v.y, v.z, v.w};
-      if (n >= OLO && n < OLO + ON) outr[f][n - OLO] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n >= OLO && n < OLO + ON) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.accum && ch0 < a.H && q >= q0 && q < q0 + kWnOutFrames && q < a.T)      // continue a previous launch's skip sum
+          o = *reinterpret_cast<const float4*>(a.out + (size_t)b * a.bs + (size_t)q * a.H + ch0);
+        outr[f][n - OLO] = f32x4{o.x, o.y, o.z, o.w};
+      }
     }
   }
   __syncthreads();                            // tile zeroed before anybody writes x into it
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
   __syncthreads();
 
   for (int l = 0; l < a.layers; ++l) {
-    const bool last = l == a.layers - 1;
+    const bool last = a.final_layer && l == a.layers - 1;      // the network's last layer has no residual half
     {   // ---- GEMM1 (k taps) + conditioning + gate -> acts tile
       f32x4 acc[MF][NF];
 #pragma unroll
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
     __syncthreads();                          // x tile updated / acts tile free for the next layer
   }
 
-  // ---- store the skip sum of the output tile
+  // ---- store the skip sum (and, when another launch continues the stack, the residual stream) of the output tile
 #pragma unroll
   for (int f = 0; f < FW; ++f) {
     const int ch0 = (wm * FW + f) * 16 + lq * 4;
@@ -808,9 +814,12 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
 #pragma unroll
     for (int n = OLO; n < OLO + ON; ++n) {
       const int q = w0 + n * 16 + lrow;
-      if (q >= q0 && q < q0 + kWnOutFrames && q < a.T)
-        *reinterpret_cast<float4*>(a.out + (size_t)b * a.bs + (size_t)q * a.H + ch0) =
+      if (q >= q0 && q < q0 + kWnOutFrames && q < a.T) {
+        const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
+        *reinterpret_cast<float4*>(a.out + off) =
             make_float4(outr[f][n - OLO][0], outr[f][n - OLO][1], outr[f][n - OLO][2], outr[f][n - OLO][3]);
+        if (a.x_out) *reinterpret_cast<float4*>(a.x_out + off) = make_float4(xr[f][n][0], xr[f][n][1], xr[f][n][2], xr[f][n][3]);
+      }
     }
   }
 }
@@ -902,7 +911,7 @@ int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, 
 
 // ---- fused pair: tile choice + dispatch
 inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
-  static const int nfs[] = {2, 4, 5, 8};
+  static const int nfs[] = {2, 4, 5, 8};     // measured at B=32: NF 5 (2 workgroups/CU) beats 4 and 8 by 7-35 %
   const int WN = kWaves / d.WM;
   const int halo1 = (d.taps - 1) * d.dil, rowbytes = d.CinP * 2;
   TileChoice best{0, 0, 0};

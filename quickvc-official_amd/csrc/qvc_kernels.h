@@ -77,6 +77,10 @@ struct WnStackArgs {
   const void* w_in[kWnMaxLayers] = {}; const void* w_rs[kWnMaxLayers] = {}; const float* b_rs[kWnMaxLayers] = {};
   const float* bbias = nullptr; int64_t bbias_bs = 0;     // + l*2H per layer
   int32_t layers = 0, taps = 1, KS = 1, nIt1 = 1;
+  // a stack may be split over several launches (less halo to recompute per launch): x_out receives the residual
+  // stream for the next launch, accum continues the skip sum already in `out`, final_layer marks the launch that
+  // holds the network's last layer (whose 1x1 has no residual half)
+  float* x_out = nullptr; int32_t accum = 0, final_layer = 1;
 };
 
 struct GemvArgs {

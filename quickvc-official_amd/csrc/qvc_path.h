@@ -62,16 +62,26 @@ struct Path {
   void wn(const WNPlan& wn, const float* bb, int64_t bb_bs) {
     const int H = P.cfg.hidden_channels;
     const int64_t bs = (int64_t)T * H;
-    if (wn_stack_ok(wn.in_conv[0], wn.layers) && be.use_wn_stack(B, T)) {
-      WnStackArgs a;
-      a.x0 = wsp<float>(W.xw); a.out = wsp<float>(W.oacc); a.bs = bs; a.T = T; a.H = H; a.HP = wn.in_conv[0].CinP;
-      for (int l = 0; l < wn.layers; ++l) {
-        a.w_in[l] = blob + wn.in_conv[l].w_off; a.w_rs[l] = blob + wn.rs_conv[l].w_off;
-        a.b_rs[l] = reinterpret_cast<const float*>(blob + wn.rs_conv[l].b_off);
+    // Whole-stack kernel, in launches of `chunk` layers: fewer layers per launch = less halo to recompute
+    // (4 layers: 48-frame window for 32 output frames; 16 layers: 96), more launches = more x round trips.
+    const int chunk = be.wn_stack_chunk(wn.layers);
+    if (chunk > 0 && wn.layers % chunk == 0 && wn_stack_ok(wn.in_conv[0], chunk) && be.use_wn_stack(B, T)) {
+      for (int l0 = 0; l0 < wn.layers; l0 += chunk) {
+        const int part = l0 / chunk;
+        WnStackArgs a;
+        a.x0 = wsp<float>(part % 2 == 0 ? W.xw : W.xw2);
+        a.out = wsp<float>(W.oacc); a.bs = bs; a.T = T; a.H = H; a.HP = wn.in_conv[0].CinP;
+        for (int l = 0; l < chunk; ++l) {
+          a.w_in[l] = blob + wn.in_conv[l0 + l].w_off; a.w_rs[l] = blob + wn.rs_conv[l0 + l].w_off;
+          a.b_rs[l] = reinterpret_cast<const float*>(blob + wn.rs_conv[l0 + l].b_off);
+        }
+        a.bbias = bb + (int64_t)l0 * 2 * H; a.bbias_bs = bb_bs;
+        a.layers = chunk; a.taps = wn.in_conv[0].taps; a.KS = wn.in_conv[0].KS(); a.nIt1 = wn.in_conv[0].nIt();
+        a.final_layer = l0 + chunk == wn.layers ? 1 : 0;
+        a.accum = l0 > 0 ? 1 : 0;
+        a.x_out = a.final_layer ? nullptr : wsp<float>(part % 2 == 0 ? W.xw2 : W.xw);
+        if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype());
       }
-      a.bbias = bb; a.bbias_bs = bb_bs;
-      a.layers = wn.layers; a.taps = wn.in_conv[0].taps; a.KS = wn.in_conv[0].KS(); a.nIt1 = wn.in_conv[0].nIt();
-      if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype());
       return;
     }
     zero(W.oacc, (int64_t)B * bs * 4);
