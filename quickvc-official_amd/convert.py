@@ -7,6 +7,11 @@ source side takes pre-extracted units -- ``src`` may be a ``.npy`` file of shape
 next to it (``x.wav`` -> ``x.npy``).  New optional flags: ``--batch`` (utterances converted per
 launch), ``--seed`` (noise), ``--dtype``.
 
+Corpus scale (BASELINE.json configs[3]): started under ``torch.distributed.run`` (one process per
+GPU) every rank converts its own static shard of the list (length-sorted round-robin,
+``dist.shard_indices``); nothing is exchanged between ranks -- each rank loads the checkpoint itself, so
+there is not even a start-up broadcast in this mode.
+
     python -m quickvc_official_amd.convert --hpfile logs/quickvc/config.json --ptfile quickvc.pth
 """
 from __future__ import annotations
@@ -19,6 +24,7 @@ import numpy as np
 import torch
 
 from .checkpoint import load_checkpoint
+from .dist import env_world, shard_indices
 from .config import get_hparams_from_file
 from .frontend import load_wav, trim, wave_to_mel
 from .model import SynthesizerTrn
@@ -33,6 +39,19 @@ def _load_units(src: str) -> torch.Tensor:
     if u.ndim != 2 or u.shape[1] != 256:
         raise ValueError(f"{path}: expected (frames, 256), got {u.shape}")
     return torch.from_numpy(u).t().unsqueeze(0)               # (1, 256, frames), data_utils_new_new.py:121-122
+
+
+def plan_batches(lengths, batch: int):
+    """Utterances of equal unit length share a launch (the path has no masks, so padding would change
+    the result near the end); returns lists of item indices, longest first."""
+    by_len = {}
+    for i, n in enumerate(lengths):
+        by_len.setdefault(int(n), []).append(i)
+    plan = []
+    for n in sorted(by_len, reverse=True):
+        group = by_len[n]
+        plan.extend(group[i:i + batch] for i in range(0, len(group), batch))
+    return plan
 
 
 def main(argv=None) -> None:
@@ -50,6 +69,8 @@ def main(argv=None) -> None:
     from scipy.io.wavfile import write
     os.makedirs(args.outdir, exist_ok=True)
     hps = get_hparams_from_file(args.hpfile)
+    rank, local_rank, world = env_world()
+    torch.cuda.set_device(local_rank)
     print("Loading model...")
     net_g = SynthesizerTrn(hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
                            **hps.model, operand_dtype=args.dtype).cuda().eval()
@@ -79,19 +100,17 @@ def main(argv=None) -> None:
                                   d.sampling_rate, d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
                 g_cache[tgt] = net_g.enc_spk.embed_utterance(mel.transpose(1, 2))
             prepared.append((title, _load_units(src), g_cache[tgt]))
-        # equal-length utterances share a launch; the rest go one by one (no masks on the path)
-        by_len = {}
-        for title, unit, g in prepared:
-            by_len.setdefault(unit.shape[-1], []).append((title, unit, g))
-        for frames, group in by_len.items():
-            for i in range(0, len(group), args.batch):
-                chunk = group[i:i + args.batch]
-                unit = torch.cat([u for _, u, _ in chunk], 0).cuda()
-                g = torch.cat([gg for _, _, gg in chunk], 0)
-                audio = net_g.infer_batch(unit, g)
-                for (title, _, _), a in zip(chunk, audio):
-                    name = f"{time.strftime('%m-%d_%H-%M', time.localtime())}_{title}.wav" if args.use_timestamp else f"{title}.wav"
-                    write(os.path.join(args.outdir, name), d.sampling_rate, a[0].float().cpu().numpy())
+        # this rank's shard of the list, then equal-length utterances share a launch
+        mine = shard_indices(len(prepared), rank, world, [p[1].shape[-1] for p in prepared])
+        prepared = [prepared[i] for i in mine]
+        for idxs in plan_batches([p[1].shape[-1] for p in prepared], args.batch):
+            chunk = [prepared[i] for i in idxs]
+            unit = torch.cat([u for _, u, _ in chunk], 0).cuda()
+            g = torch.cat([gg for _, _, gg in chunk], 0)
+            audio = net_g.infer_batch(unit, g)
+            for (title, _, _), a in zip(chunk, audio):
+                name = f"{time.strftime('%m-%d_%H-%M', time.localtime())}_{title}.wav" if args.use_timestamp else f"{title}.wav"
+                write(os.path.join(args.outdir, name), d.sampling_rate, a[0].float().cpu().numpy())
 
 
 if __name__ == "__main__":

@@ -177,3 +177,30 @@ def test_world_size_2_broadcast_and_sharding_gloo(tmp_path):
     assert all(d["ok"] for d in outs)
     assert outs[0]["mine"] == [0, 2, 4, 6, 8] and outs[1]["mine"] == [1, 3, 5, 7, 9]
     assert all(d["wall"] == 2.0 and d["total"] == 10.0 for d in outs)
+
+
+def test_frontend_and_cli_planning():
+    """Host-side pieces around the path (parity-unpinned: librosa is absent, so these
+    check the published definitions' properties, not the reference's numbers)."""
+    from quickvc_official_amd import frontend as F
+    from quickvc_official_amd.convert import plan_batches
+    basis = F.mel_basis(16000, 1280, 80, 0.0, None)
+    assert basis.shape == (80, 641) and (basis >= 0).all()
+    peaks = basis.argmax(axis=1)
+    assert (np.diff(peaks) > 0).all()                              # centre frequencies increase
+    # Slaney normalisation: every triangle has (almost) the same area in Hz
+    areas = basis.sum(axis=1) * (8000.0 / 640)
+    assert np.allclose(areas, 1.0, atol=0.08)
+    wav = np.zeros(16000, dtype=np.float32)
+    wav[4000:12000] = 0.5 * np.sin(2 * np.pi * 220 * np.arange(8000) / 16000)
+    t = F.trim(wav, top_db=20)
+    assert 7000 <= len(t) <= 10500 and len(t) < len(wav)            # silence dropped, tone kept (512-sample hops)
+    mel = F.wave_to_mel(torch.from_numpy(wav).unsqueeze(0), 1280, 80, 16000, 320, 1280, 0.0, None)
+    assert mel.shape == (1, 80, 50) and torch.isfinite(mel).all()  # 16000 samples / hop 320 (mel_processing.py:79-98)
+    assert float(mel[:, :, 20:30].max()) > float(mel[:, :, :5].max()) + 3.0
+    plan = plan_batches([81, 250, 81, 250, 250, 120], batch=2)
+    assert plan == [[1, 3], [4], [5], [0, 2]]
+    ref = os.path.join(ROOT, "..", "reference", "test_data", "p225_001.wav")
+    if os.path.exists(ref):                                         # container only: the reference's own demo input
+        w = F.load_wav(ref, 16000)
+        assert w.dtype == np.float32 and abs(len(w) - 26007) <= 1 and np.abs(w).max() <= 1.0
