@@ -911,13 +911,13 @@ int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, 
 
 // ---- fused pair: tile choice + dispatch
 inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
-  static const int nfs[] = {2, 4, 5, 8};     // measured at B=32: NF 5 (2 workgroups/CU) beats 4 and 8 by 7-35 %
+  static const int nfs[] = {2, 4, 5, 8, 10}; // measured at B=32, MF 4: NF 5 (2 workgroups/CU) beats 4 and 8 by 7-35 %
   const int WN = kWaves / d.WM;
   const int halo1 = (d.taps - 1) * d.dil, rowbytes = d.CinP * 2;
   TileChoice best{0, 0, 0};
   double best_cost = 1e300;
   for (int NF : nfs) {
-    if (d.MF * (NF + 1) * 4 > 160) continue;
+    if (d.MF * (NF + 1) * 4 > 160 || (NF == 10 && d.MF > 2)) continue;
     const size_t lds = (size_t)(WN * (NF + 1) * 16 + halo1) * rowbytes;
     if (lds > 160 * 1024) continue;
     const int NT = WN * NF * 16;
@@ -956,6 +956,7 @@ inline int launch_pair_nf(const ConvDesc& d, const PairArgs& a, int batch, hipSt
     case 4: return launch_pair_one<T, MF, 4, WM>(a, batch, tc.lds, stream);
     case 5: return launch_pair_one<T, MF, 5, WM>(a, batch, tc.lds, stream);
     case 8: if constexpr (MF * 9 * 4 <= 160) return launch_pair_one<T, MF, 8, WM>(a, batch, tc.lds, stream); break;
+    case 10: if constexpr (MF * 11 * 4 <= 96) return launch_pair_one<T, MF, 10, WM>(a, batch, tc.lds, stream); break;
     default: break;
   }
   return QVC_ERR_BAD_CONFIG;

@@ -95,11 +95,13 @@ int main(int argc, char** argv) {
     CK(hipFree(dw));
   }
   // ---- fused ResBlock pairs
-  struct PShape { const char* name; int C, T, k, dil; };
+  struct PShape { const char* name; int C, T, k, dil; int force_mf, force_wm; };
   std::vector<PShape> pshapes = {{"pair s2 k3 d1", 128, 5000, 3, 1}, {"pair s2 k7 d3", 128, 5000, 7, 3}, {"pair s2 k11 d5", 128, 5000, 11, 5},
+                                 {"s2 k3 MF2WM4", 128, 5000, 3, 1, 2, 4}, {"s2 k7 MF2WM4", 128, 5000, 7, 3, 2, 4}, {"s2 k11 MF2WM4", 128, 5000, 11, 5, 2, 4},
                                  {"pair s1 k3 d1", 256, 1250, 3, 1}, {"pair s1 k7 d3", 256, 1250, 7, 3}, {"pair s1 k11 d5", 256, 1250, 11, 5}};
   for (const PShape& s : pshapes) {
     ConvDesc d1 = make_conv(s.C, s.C, s.k, s.dil), d2 = make_conv(s.C, s.C, s.k, 1);
+    if (s.force_mf) { d1.MF = d2.MF = s.force_mf; d1.WM = d2.WM = s.force_wm; d1.nchunk = d2.nchunk = ceil_div(s.C, s.force_mf * s.force_wm * 16); }
     d1.w_off = 0; d1.b_off = align_up(d1.w_bytes(), 256);
     size_t wb = d1.b_off + d1.b_bytes();
     std::vector<char> hw(wb);
