@@ -227,12 +227,26 @@ struct EmuBackend {
   bool use_wn_stack(int, int) const { return true; }
   int wn_stack_chunk(int layers) const { return layers % 4 == 0 ? 4 : layers; }
   // whole stack = the layers one after the other (x ping-pong in temporaries)
-  int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& s, int B, int dtype) {
-    std::vector<float> xa(s.x0, s.x0 + (size_t)B * s.bs), xb((size_t)B * s.bs, 0.f);
-    if (!s.accum) std::memset(s.out, 0, (size_t)B * s.bs * 4);
+  int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& s, int B, int dtype,
+               const ConvDesc* dpre, const ConvDesc* dpost) {
+    auto fill = [](ConvArgs& a, const ConvDesc& d) {
+      a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left; a.KS = d.KS(); a.nIt = d.nIt();
+      a.nchunk = d.nchunk; a.M = d.M; a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout; };
+    std::vector<float> xa((size_t)B * s.bs, 0.f), xb((size_t)B * s.bs, 0.f), outbuf;
+    float* out = s.out;
+    if (s.w_pre) {   // fused pre 1x1: x0 = W_pre * z[in slice] + b
+      ConvArgs a; fill(a, *dpre);
+      a.w = s.w_pre; a.bias = s.b_pre; a.x = s.z; a.x_kind = XK_F32_FM; a.x_bs = s.z_bs; a.x_ts = s.z_ts; a.x_c0 = s.pre_c0;
+      a.T_in = s.T; a.Nq = s.T; a.T_out = s.T; a.y32 = xa.data(); a.y32_bs = s.bs; a.y32_ts = s.H;
+      conv(*dpre, a, B, EPI_STD, dtype);
+    } else {
+      std::memcpy(xa.data(), s.x0, (size_t)B * s.bs * 4);
+    }
+    if (s.w_post) { outbuf.assign((size_t)B * s.bs, 0.f); out = outbuf.data(); }
+    else if (!s.accum) std::memset(out, 0, (size_t)B * s.bs * 4);
     for (int l = 0; l < s.layers; ++l) {
       WnArgs a;
-      a.x_in = (l % 2 ? xb : xa).data(); a.x_out = (l % 2 ? xa : xb).data(); a.oacc = s.out;
+      a.x_in = (l % 2 ? xb : xa).data(); a.x_out = (l % 2 ? xa : xb).data(); a.oacc = out;
       a.bs = s.bs; a.T = s.T; a.H = s.H; a.HP = s.HP;
       a.w_in = s.w_in[l]; a.w_rs = s.w_rs[l]; a.b_rs = s.b_rs[l];
       a.bbias = s.bbias + (size_t)l * 2 * s.H; a.bbias_bs = s.bbias_bs;
@@ -240,6 +254,14 @@ struct EmuBackend {
       wn(din, a.last ? drs_last : drs, a, B, dtype);
     }
     if (s.x_out) std::memcpy(s.x_out, (s.layers % 2 ? xb : xa).data(), (size_t)B * s.bs * 4);
+    if (s.w_post) {  // fused post 1x1: z[out slice] -= W_post * out + b
+      ConvArgs a; fill(a, *dpost);
+      a.w = s.w_post; a.bias = s.b_post; a.x = out; a.x_kind = XK_F32_FM; a.x_bs = s.bs; a.x_ts = s.H;
+      a.T_in = s.T; a.Nq = s.T; a.T_out = s.T;
+      a.res = s.z; a.res_bs = s.z_bs; a.res_ts = s.z_ts; a.res_c0 = s.post_c0; a.res_sign = -1.f;
+      a.y32 = s.z; a.y32_bs = s.z_bs; a.y32_ts = s.z_ts; a.y32_c0 = s.post_c0;
+      conv(*dpost, a, B, EPI_STD, dtype);
+    }
     return QVC_OK;
   }
   // fused pair = the two convs back to back with the intermediate rounded to the operand type

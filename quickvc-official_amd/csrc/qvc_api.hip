@@ -71,7 +71,7 @@ struct HipBackend {
   // the stack kernel trades 3x recomputed halo for one launch: right when its grid fills the machine
   bool use_wn_stack(int batch, int frames) const { return (long)batch * ceil_div(frames, kWnOutFrames) >= 128; }
   int wn_stack_chunk(int layers) const { return wn_chunk(layers); }
-  int wn_stack(const ConvDesc& din, const ConvDesc&, const ConvDesc&, const WnStackArgs& a, int batch, int dtype) { return launch_wn_stack(din, a, batch, dtype, stream); }
+  int wn_stack(const ConvDesc& din, const ConvDesc&, const ConvDesc&, const WnStackArgs& a, int batch, int dtype, const ConvDesc*, const ConvDesc*) { return launch_wn_stack(din, a, batch, dtype, stream); }
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
@@ -139,15 +139,18 @@ struct TimedBackend {
   }
   bool use_wn_stack(int batch, int frames) const { return (long)batch * ceil_div(frames, kWnOutFrames) >= 128; }
   int wn_stack_chunk(int layers) const { return wn_chunk(layers); }
-  int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& a, int batch, int dtype) {
+  int wn_stack(const ConvDesc& din, const ConvDesc& drs, const ConvDesc& drs_last, const WnStackArgs& a, int batch, int dtype,
+               const ConvDesc* dpre, const ConvDesc* dpost) {
     if (ev.empty()) mark();
     int st = launch_wn_stack(din, a, batch, dtype, stream);
     mark();
     char name[48];
-    std::snprintf(name, sizeof(name), "wn_stack<%s,FW%d,L%d>", dtype == QVC_F16 ? "f16" : "bf16", din.MF / 2, a.layers);
+    std::snprintf(name, sizeof(name), "wn_stack<%s,FW%d,L%d%s>", dtype == QVC_F16 ? "f16" : "bf16", din.MF / 2, a.layers,
+                  dpre ? ",pre+post" : "");
     const double cols = (double)batch * a.T;
     const double fl = 2.0 * cols * a.H * (a.layers * 2.0 * a.H * a.taps + (a.layers - (a.final_layer ? 1 : 0)) * (double)drs.M + (a.final_layer ? (double)drs_last.M : 0.0));
-    note(name, fl, cols * a.H * 8 + a.layers * ((double)din.w_bytes() + (double)drs.w_bytes()));
+    const double fuse_fl = (dpre ? 2.0 * cols * dpre->M * dpre->Cin : 0.0) + (dpost ? 2.0 * cols * dpost->M * dpost->Cin : 0.0);
+    note(name, fl + fuse_fl, cols * a.H * 8 + a.layers * ((double)din.w_bytes() + (double)drs.w_bytes()));
     return st;
   }
   int gemv(const GemvArgs& a) { if (ev.empty()) mark(); int st = launch_gemv(a, stream); mark();

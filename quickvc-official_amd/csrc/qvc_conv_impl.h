@@ -653,7 +653,8 @@ __global__ __launch_bounds__(256) void wn_layer_kernel(const WnArgs a) {
 
 
 // ------------------------------------------------------------------ whole WaveNet stack, one launch
-template <typename T, int FW, int NF>
+// PM = A fragments per wave of the optional fused post conv (0: none)
+template <typename T, int FW, int NF, int PM>
 __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
@@ -683,6 +684,47 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
 
   // x residual stream and skip sum of this wave's channels live in registers for the whole stack
   f32x4 xr[FW][NF], outr[FW][ON];
+  if (a.w_pre) {
+    // fused `pre` 1x1 (modules.py:212): stage the z slice of the window into the (still unused) acts tile,
+    // one small GEMM, and the result IS the residual stream -- no launch, no round trip through memory
+    const int pcpr = a.pre_KS * 4;                              // 16-byte chunks per staged row
+    for (int i = tid; i < (NB * rowbytes) >> 4; i += 256) reinterpret_cast<uint4*>(acts)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const float* zb = a.z + (size_t)b * a.z_bs + a.pre_c0;
+    for (int idx = tid; idx < NB * pcpr; idx += 256) {
+      const int r = idx / pcpr, c8 = idx - r * pcpr;
+      const int q = w0 + r;
+      if (q >= 0 && q < a.T && c8 * 8 < a.pre_cin) {
+        const float4* p = reinterpret_cast<const float4*>(zb + (size_t)q * a.z_ts + c8 * 8);
+        const float4 v0 = p[0], v1 = p[1];
+        frag h;
+        h[0] = O::cvt(v0.x); h[1] = O::cvt(v0.y); h[2] = O::cvt(v0.z); h[3] = O::cvt(v0.w);
+        h[4] = O::cvt(v1.x); h[5] = O::cvt(v1.y); h[6] = O::cvt(v1.z); h[7] = O::cvt(v1.w);
+        *reinterpret_cast<frag*>(acts + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = h;
+      }
+    }
+    __syncthreads();
+    f32x4 pacc[FW][NF];
+#pragma unroll
+    for (int f = 0; f < FW; ++f)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) pacc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const frag* app = static_cast<const frag*>(a.w_pre) + ((size_t)wm * a.pre_KS * FW) * 64 + lane;
+    gemm_loop<T, FW, NF, QVC_PF_CONV>(pacc, app, a.pre_KS, a.pre_KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const int ch0 = (wm * FW + f) * 16 + lq * 4;
+      float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ch0 < a.H) bp = *reinterpret_cast<const float4*>(a.b_pre + ch0);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = w0 + n * 16 + lrow;
+        const bool in = ch0 < a.H && q >= 0 && q < a.T;
+        xr[f][n] = in ? f32x4{pacc[f][n][0] + bp.x, pacc[f][n][1] + bp.y, pacc[f][n][2] + bp.z, pacc[f][n][3] + bp.w}
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
 #pragma unroll
   for (int f = 0; f < FW; ++f) {
     const int ch0 = (wm * FW + f) * 16 + lq * 4;
@@ -690,8 +732,10 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
     for (int n = 0; n < NF; ++n) {
       const int q = w0 + n * 16 + lrow;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ch0 < a.H && q >= 0 && q < a.T) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
-      xr[f][n] = f32x4{v.x, v.y, v.z, v.w};
+      if (!a.w_pre) {
+        if (ch0 < a.H && q >= 0 && q < a.T) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
+        xr[f][n] = f32x4{v.x, v.y, v.z, v.w};
+      }
       if (n >= OLO && n < OLO + ON) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.accum && ch0 < a.H && q >= q0 && q < q0 + kWnOutFrames && q < a.T)      // continue a previous launch's skip sum
@@ -806,6 +850,55 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
     __syncthreads();                          // x tile updated / acts tile free for the next layer
   }
 
+  if constexpr (PM > 0) {
+    if (a.w_post) {
+      // fused `post` 1x1 + coupling update (modules.py:214-217): the skip sum goes (operand type) into the acts
+      // tile, one small GEMM, and z[:, post slice] -= m for the output frames.  The skip sum itself is not stored.
+#pragma unroll
+      for (int f = 0; f < FW; ++f) {
+        const int ch0 = (wm * FW + f) * 16 + lq * 4;
+        if (ch0 >= a.HP) continue;
+#pragma unroll
+        for (int n = OLO; n < OLO + ON; ++n) {
+          const int j = n * 16 + lrow;
+          quad h;
+          if (ch0 < a.H) {
+            h[0] = O::cvt(outr[f][n - OLO][0]); h[1] = O::cvt(outr[f][n - OLO][1]);
+            h[2] = O::cvt(outr[f][n - OLO][2]); h[3] = O::cvt(outr[f][n - OLO][3]);
+          } else {
+            h[0] = h[1] = h[2] = h[3] = (T)0.f;
+          }
+          *reinterpret_cast<quad*>(acts + j * rowbytes + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = h;
+        }
+      }
+      __syncthreads();
+      f32x4 qacc[PM][ON];
+#pragma unroll
+      for (int m = 0; m < PM; ++m)
+#pragma unroll
+        for (int n = 0; n < ON; ++n) qacc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const frag* apq = static_cast<const frag*>(a.w_post) + ((size_t)wm * a.KS * PM) * 64 + lane;
+      gemm_loop<T, PM, ON, QVC_PF_CONV>(qacc, apq, a.KS, a.KS, 1, acts, rowbytes, sm, OLO * 16 + lrow, lq, 0);
+#pragma unroll
+      for (int m = 0; m < PM; ++m) {
+        const int v = (wm * PM + m) * 16 + lq * 4;
+        if (v >= a.post_m) continue;
+        const float4 bq = *reinterpret_cast<const float4*>(a.b_post + v);
+#pragma unroll
+        for (int n = 0; n < ON; ++n) {
+          const int q = w0 + (OLO + n) * 16 + lrow;
+          if (q >= q0 && q < q0 + kWnOutFrames && q < a.T) {
+            float* p = a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v;
+            float4 zz = *reinterpret_cast<const float4*>(p);
+            zz.x -= qacc[m][n][0] + bq.x; zz.y -= qacc[m][n][1] + bq.y;
+            zz.z -= qacc[m][n][2] + bq.z; zz.w -= qacc[m][n][3] + bq.w;
+            *reinterpret_cast<float4*>(p) = zz;
+          }
+        }
+      }
+      return;
+    }
+  }
   // ---- store the skip sum (and, when another launch continues the stack, the residual stream) of the output tile
 #pragma unroll
   for (int f = 0; f < FW; ++f) {
@@ -1010,9 +1103,9 @@ int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* strea
 }
 
 // ---- whole-stack WaveNet dispatch
-template <typename T, int FW, int NF>
-inline int launch_wn_stack_one(const WnStackArgs& a, int batch, hipStream_t stream) {
-  auto kern = wn_stack_kernel<T, FW, NF>;
+template <typename T, int FW, int NF, int PM>
+inline int launch_wn_stack_pm(const WnStackArgs& a, int batch, hipStream_t stream) {
+  auto kern = wn_stack_kernel<T, FW, NF, PM>;
   const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1022,6 +1115,15 @@ inline int launch_wn_stack_one(const WnStackArgs& a, int batch, hipStream_t stre
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, kWnOutFrames), (unsigned)batch), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+template <typename T, int FW, int NF>
+inline int launch_wn_stack_one(const WnStackArgs& a, int batch, hipStream_t stream) {
+  const int pm = a.w_post ? a.post_mf : 0;
+  if (pm == 0) return launch_wn_stack_pm<T, FW, NF, 0>(a, batch, stream);
+  if (pm == 1) return launch_wn_stack_pm<T, FW, NF, 1>(a, batch, stream);
+  if (pm == 2) return launch_wn_stack_pm<T, FW, NF, 2>(a, batch, stream);
+  return QVC_ERR_BAD_CONFIG;
 }
 
 template <typename T>

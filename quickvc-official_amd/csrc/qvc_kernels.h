@@ -81,6 +81,12 @@ struct WnStackArgs {
   // stream for the next launch, accum continues the skip sum already in `out`, final_layer marks the launch that
   // holds the network's last layer (whose 1x1 has no residual half)
   float* x_out = nullptr; int32_t accum = 0, final_layer = 1;
+  // Optional fused 1x1 convs of a coupling layer (modules.py:212-217): with w_pre the stack input is computed in the
+  // kernel, x0 = W_pre * z[:, pre_c0 : pre_c0+pre_cin] + b_pre; with w_post the kernel ends with
+  // z[:, post_c0 : post_c0+post_m] -= W_post * out + b_post (in place; the two channel slices are disjoint).
+  const void* w_pre = nullptr; const float* b_pre = nullptr; int32_t pre_cin = 0, pre_c0 = 0, pre_KS = 0;
+  const void* w_post = nullptr; const float* b_post = nullptr; int32_t post_m = 0, post_c0 = 0, post_mf = 0;
+  float* z = nullptr; int64_t z_bs = 0; int32_t z_ts = 0;
 };
 
 struct GemvArgs {

@@ -80,7 +80,7 @@ struct Path {
         a.final_layer = l0 + chunk == wn.layers ? 1 : 0;
         a.accum = l0 > 0 ? 1 : 0;
         a.x_out = a.final_layer ? nullptr : wsp<float>(part % 2 == 0 ? W.xw2 : W.xw);
-        if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype());
+        if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype(), nullptr, nullptr);
       }
       return;
     }
@@ -131,6 +131,26 @@ struct Path {
     const int H = c.hidden_channels, C = c.inter_channels;
     const float* bb = wsp<float>(W.bb);
     for (const FlowStepPlan& f : P.flow) {
+      const ConvDesc& din = f.wn.in_conv[0];
+      if (f.wn.layers == be.wn_stack_chunk(f.wn.layers) && wn_fuse_ok(din, f.pre, f.post, f.wn.layers) && be.use_wn_stack(B, T)) {
+        // the whole coupling layer in ONE launch: pre 1x1 -> 4 WaveNet layers -> post 1x1 -> x1 -= m
+        WnStackArgs a;
+        a.bs = (int64_t)T * H; a.T = T; a.H = H; a.HP = din.CinP;
+        for (int l = 0; l < f.wn.layers; ++l) {
+          a.w_in[l] = blob + f.wn.in_conv[l].w_off; a.w_rs[l] = blob + f.wn.rs_conv[l].w_off;
+          a.b_rs[l] = reinterpret_cast<const float*>(blob + f.wn.rs_conv[l].b_off);
+        }
+        a.bbias = bb + f.cond_row0; a.bbias_bs = P.cond_rows;
+        a.layers = f.wn.layers; a.taps = din.taps; a.KS = din.KS(); a.nIt1 = din.nIt();
+        a.w_pre = blob + f.pre.w_off; a.b_pre = reinterpret_cast<const float*>(blob + f.pre.b_off);
+        a.pre_cin = f.pre.Cin; a.pre_c0 = f.in_c0; a.pre_KS = f.pre.KS();
+        a.w_post = blob + f.post.w_off; a.b_post = reinterpret_cast<const float*>(blob + f.post.b_off);
+        a.post_m = f.post.M; a.post_c0 = f.out_c0; a.post_mf = f.post.MF;
+        a.z = z; a.z_bs = (int64_t)T * C; a.z_ts = C;
+        if (status == QVC_OK)
+          status = be.wn_stack(din, f.wn.rs_conv[0], f.wn.rs_conv[f.wn.layers - 1], a, B, dtype(), &f.pre, &f.post);
+        continue;
+      }
       {
         ConvArgs a = args(f.pre);
         a.x = z; a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * C; a.x_ts = C; a.x_c0 = f.in_c0; a.T_in = T;

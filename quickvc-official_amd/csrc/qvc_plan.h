@@ -105,6 +105,12 @@ inline bool wn_stack_ok(const ConvDesc& din, int layers) {
   return din.gau && din.WM == 4 && din.nchunk == 1 && layers <= 16 && (nf == 3 || nf == 6) && cols_ok && fw >= 1 && fw <= 3;
 }
 
+// Can a coupling layer's pre / post 1x1 convs ride inside its whole-stack launch?
+inline bool wn_fuse_ok(const ConvDesc& din, const ConvDesc& pre, const ConvDesc& post, int layers) {
+  return wn_stack_ok(din, layers) && pre.WM == kWaves && pre.MF == din.MF / 2 && pre.nchunk == 1 && pre.CinP <= din.CinP &&
+         post.WM == kWaves && post.nchunk == 1 && (post.MF == 1 || post.MF == 2) && post.CinP == din.CinP;
+}
+
 struct WNPlan {
   int32_t layers = 0;
   std::vector<ConvDesc> in_conv;   // k-tap h -> 2h, GAU row order; bias lives in the cond/bias table
@@ -236,9 +242,15 @@ inline Plan build_plan(const qvc_config& c) {
     f.flipped = flipped ? 1 : 0;
     f.in_c0 = flipped ? C / 2 : 0;
     f.out_c0 = flipped ? 0 : C / 2;
-    f.pre = make_conv(H, C / 2, 1, 1); place(f.pre);
+    // pre / post share the WaveNet kernels' channel ownership (4 waves along M) so that they can run inside
+    // the whole-stack launch: pre's rows = the stack's residual-stream rows, post reads the skip sum
+    f.pre = make_conv(H, C / 2, 1, 1);
+    f.pre.WM = kWaves; f.pre.MF = ceil_div(ceil_div(H, 16), kWaves); f.pre.nchunk = 1;
+    place(f.pre);
     make_wn(f.wn, c.flow_layers);
-    f.post = make_conv(C / 2, H, 1, 1); place(f.post);
+    f.post = make_conv(C / 2, H, 1, 1);
+    f.post.WM = kWaves; f.post.MF = ceil_div(ceil_div(C / 2, 16), kWaves); f.post.nchunk = 1;
+    place(f.post);
     f.cond_row0 = cond_rows; cond_rows += c.flow_layers * 2 * H;
     P.flow.push_back(f);
   }
