@@ -95,7 +95,15 @@ struct EmuBackend {
             if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)s * a.x_ts + a.x_c0 + c], a.slope_in), dtype);
           } else if (a.x_kind == XK_OP_FM) {
             ok = ti >= 0 && ti < a.T_in;
-            if (ok) { uint16_t h = static_cast<const uint16_t*>(a.x)[(size_t)b * a.x_bs + (size_t)ti * a.x_ts + a.x_c0 + c]; v = dtype == QVC_F16 ? from_f16(h) : from_bf16(h); if (a.slope_in != 1.f) v = round_op(lrelu(v, a.slope_in), dtype); }
+            if (a.x2) {   // MRF mean taken on the fly (reflect applies as in the fp32 path)
+              int s2; bool ok2;
+              if (a.reflect) { ok2 = ti >= 0 && ti <= a.T_in; s2 = ti == 0 ? 1 : ti - 1; } else { ok2 = ok; s2 = ti; }
+              if (ok2) {
+                const size_t o = (size_t)b * a.x_bs + (size_t)s2 * a.x_ts + a.x_c0 + c;
+                auto get = [&](const void* p) { const uint16_t h = static_cast<const uint16_t*>(p)[o]; return dtype == QVC_F16 ? from_f16(h) : from_bf16(h); };
+                v = round_op(lrelu((get(a.x) + get(a.x2) + get(a.x3)) * (1.f / 3.f), a.slope_in), dtype);
+              }
+            } else if (ok) { uint16_t h = static_cast<const uint16_t*>(a.x)[(size_t)b * a.x_bs + (size_t)ti * a.x_ts + a.x_c0 + c]; v = dtype == QVC_F16 ? from_f16(h) : from_bf16(h); if (a.slope_in != 1.f) v = round_op(lrelu(v, a.slope_in), dtype); }
           } else {
             ok = ti >= 0 && ti < a.T_in;
             if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)c * a.x_ts + ti], a.slope_in), dtype);
@@ -277,8 +285,7 @@ struct EmuBackend {
     ConvArgs a2; fill(a2, d2);
     a2.w = p.w2; a2.bias = p.b2; a2.x = xt.data(); a2.x_kind = XK_OP_FM; a2.x_bs = p.bs; a2.x_ts = p.C; a2.T_in = p.T;
     a2.Nq = p.T; a2.T_out = p.T; a2.res16 = p.x; a2.res_bs = p.bs; a2.res_ts = p.C;
-    if (p.m32) { a2.y32 = p.m32; a2.y32_bs = p.bs; a2.y32_ts = p.C; a2.y_scale = p.scale; a2.y_accum = p.accum; }
-    else { a2.y16 = p.y; a2.y16_bs = p.bs; a2.y16_ts = p.C; a2.slope_out = 1.f; }
+    a2.y16 = p.y; a2.y16_bs = p.bs; a2.y16_ts = p.C; a2.slope_out = 1.f;
     conv(d2, a2, B, EPI_STD, dtype);
     return QVC_OK;
   }
@@ -387,8 +394,8 @@ int64_t qvc_emu_tap_offset(const qvc_config* cfg, int32_t batch, int32_t frames,
   switch (which) {
     case 0: return W.z;
     case 1: return W.post;
-    case 2: return W.m[0];
-    case 3: return W.m.size() > 1 ? W.m[1] : -1;
+    case 2: return W.ra[0][0];   // final tensor of ResBlock 0, stage 0 (operand type)
+    case 3: return -1;
     case 4: return W.u[0];   // operand type since the fused-pair path
     case 5: return W.stats;
     default: return -1;

@@ -48,10 +48,9 @@ struct Branches {
   void branch_done(int j) { if (aux && j < 3 && hipEventRecord(aux->done[j], of(j)) != hipSuccess) ok = false; }
   void wait_branch_done(int j) { if (aux && j < 3 && hipStreamWaitEvent(cur, aux->done[j], 0) != hipSuccess) ok = false; }
   void join(int n) {
-    if (aux) {   // the mean updates are chained, so the last branch finishing implies all of them; branches > 2 ran on main
-      const int lastb = n - 1 <= 2 ? n - 1 : 2;
-      if (lastb >= 1 && hipStreamWaitEvent(main, aux->done[lastb], 0) != hipSuccess) ok = false;
-    }
+    if (aux)     // branches 1 and 2 ran on the auxiliary streams (further ones, and branch 0, on main)
+      for (int j = 1; j < n && j <= 2; ++j)
+        if (hipStreamWaitEvent(main, aux->done[j], 0) != hipSuccess) ok = false;
     cur = main;
   }
 };
@@ -101,7 +100,7 @@ struct TimedBackend {
     // algorithmic work: a transposed conv does k MACs per (input frame, ci, co), a conv taps MACs per output
     const double macs = d.up_s > 1 ? (double)batch * a.T_in * d.Cin * d.Cout * (double)d.ksize
                                    : (double)batch * a.Nq * (double)d.M * d.taps * d.Cin;
-    const double in_b = (double)batch * a.T_in * d.Cin * (a.x_kind == XK_OP_FM ? 2 : 4);
+    const double in_b = (double)batch * a.T_in * d.Cin * (a.x_kind == XK_OP_FM ? 2 : 4) * (a.x2 ? 3 : 1);
     double out_b = 0;
     const double outs = (double)batch * a.T_out * d.Cout;
     if (epi == EPI_GAU) out_b = (double)batch * a.Nq * a.gau_H * 2;
@@ -123,7 +122,7 @@ struct TimedBackend {
     char name[48];
     std::snprintf(name, sizeof(name), "rbpair<%s,MF%d,NF%d,WM%d>", dtype == QVC_F16 ? "f16" : "bf16", d1.MF, nf, d1.WM);
     const double outs = (double)batch * a.T * a.C;
-    note(name, 2.0 * 2.0 * outs * a.C * a.k, outs * 2 * 2 + outs * (a.m32 ? (a.accum ? 8 : 4) : 2) + (double)d1.w_bytes() + (double)d2.w_bytes());
+    note(name, 2.0 * 2.0 * outs * a.C * a.k, outs * 2 * 3 + (double)d1.w_bytes() + (double)d2.w_bytes());
     return st;
   }
   int wn(const ConvDesc& din, const ConvDesc& drs, const WnArgs& a, int batch, int dtype) {

@@ -225,6 +225,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         *reinterpret_cast<frag*>(smem + dst[u]) = h;
       }
     }
+  } else if (a.x_kind == XK_OP_FM && a.x2) {
+    // mean of three operand-type tensors (MRF average taken by the consumer), then the activation
+    const size_t boff = (size_t)b * a.x_bs + a.x_c0;
+    const T* xb = static_cast<const T*>(a.x) + boff;
+    const T* xb2 = static_cast<const T*>(a.x2) + boff;
+    const T* xb3 = static_cast<const T*>(a.x3) + boff;
+    const float slope = a.slope_in;
+    const int total = R * cpr;
+    for (int base = tid; base < total; base += 256 * kU) {
+      uint4 v1[kU], v2[kU], v3[kU];
+      int dst[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * 256;
+        const int r = idx / cpr, c8 = idx - r * cpr;
+        const int ti = t_base + r;
+        bool ok; int src;
+        if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; src = ti == 0 ? 1 : ti - 1; }
+        else { ok = ti >= 0 && ti < a.T_in; src = ti; }
+        ok = ok && idx < total && (c8 * 8 < a.Cin);
+        v1[u] = make_uint4(0u, 0u, 0u, 0u); v2[u] = v1[u]; v3[u] = v1[u];
+        if (ok) {
+          const size_t o = (size_t)src * a.x_ts + c8 * 8;
+          v1[u] = *reinterpret_cast<const uint4*>(xb + o);
+          v2[u] = *reinterpret_cast<const uint4*>(xb2 + o);
+          v3[u] = *reinterpret_cast<const uint4*>(xb3 + o);
+        }
+        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (dst[u] < 0) continue;
+        frag h1, h2, h3, h;
+        __builtin_memcpy(&h1, &v1[u], 16); __builtin_memcpy(&h2, &v2[u], 16); __builtin_memcpy(&h3, &v3[u], 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          h[i] = O::cvt(lrelu(((float)h1[i] + (float)h2[i] + (float)h3[i]) * (1.f / 3.f), slope));
+        *reinterpret_cast<frag*>(smem + dst[u]) = h;
+      }
+    }
   } else if (a.x_kind == XK_OP_FM) {
     const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.x_bs + a.x_c0;
     const int total = R * cpr;
@@ -378,7 +418,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // y = x + conv2(lrelu(conv1(lrelu(x))))  (modules.py:148-153) in ONE kernel.  The activated input tile
 // is staged once; GEMM1 produces the intermediate for NT + 2*h2 frames (its own 'same' halo), which
 // after bias + leaky-ReLU OVERWRITES the input tile in LDS (the input is dead by then), GEMM2 runs
-// from there, and the epilogue adds the raw residual.  Compared with two launches this removes the
+// from there, and the epilogue adds the raw residual and stores the operand-type result.  Compared with two launches this removes the
 // intermediate's HBM round trip and one staging pass; the price is NF+1 instead of NF column
 // fragments in GEMM1.  The residual stream is carried in the operand type (costs 0.35 dB).
 template <typename T, int MF, int NF, int WM>
@@ -486,19 +526,9 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
         const quad rr = *reinterpret_cast<const quad*>(static_cast<const T*>(a.x) + off);
         float4 val = make_float4(acc[m][n][0] + bias.x + (float)rr[0], acc[m][n][1] + bias.y + (float)rr[1],
                                  acc[m][n][2] + bias.z + (float)rr[2], acc[m][n][3] + bias.w + (float)rr[3]);
-        if (a.m32) {
-          float* p = a.m32 + off;
-          float4 out = make_float4(val.x * a.scale, val.y * a.scale, val.z * a.scale, val.w * a.scale);
-          if (a.accum) {
-            const float4 old = *reinterpret_cast<const float4*>(p);
-            out.x += old.x; out.y += old.y; out.z += old.z; out.w += old.w;
-          }
-          *reinterpret_cast<float4*>(p) = out;
-        } else {
-          quad h;
-          h[0] = O::cvt(val.x); h[1] = O::cvt(val.y); h[2] = O::cvt(val.z); h[3] = O::cvt(val.w);
-          *reinterpret_cast<quad*>(static_cast<T*>(a.y) + off) = h;
-        }
+        quad h;
+        h[0] = O::cvt(val.x); h[1] = O::cvt(val.y); h[2] = O::cvt(val.z); h[3] = O::cvt(val.w);
+        *reinterpret_cast<quad*>(static_cast<T*>(a.y) + off) = h;
       }
     }
   }
@@ -928,6 +958,9 @@ inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* n
   double best_cost = 1e300;
   for (int i = 0; i < n_nf; ++i) {
     const int NF = nf_list[i];
+#ifdef QVC_FORCE_NF
+    if (NF != QVC_FORCE_NF) continue;                           // developer sweep (tools/conv_bench)
+#endif
     if (d.MF * NF * 4 > 160) continue;                          // accumulator registers
     const int NT = WN * NF * 16;
     const size_t lds = (size_t)(NT + halo) * rowbytes;

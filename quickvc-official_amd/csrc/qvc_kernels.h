@@ -21,6 +21,9 @@ struct ConvArgs {
   int32_t x_c0 = 0;        // first channel of the slice (frame-major)
   int32_t Cin = 0, CinP = 0, T_in = 0;
   float slope_in = 1.f;    // leaky-ReLU slope applied while staging (1 = identity)
+  // XK_OP_FM only: with x2/x3 set the staged value is act(mean(x, x2, x3)) -- the MRF average of the three
+  // ResBlock outputs (models.py:378-384) is taken on the fly by its consumer, in fp32
+  const void* x2 = nullptr; const void* x3 = nullptr;
   int32_t reflect = 0;     // 1: ReflectionPad1d((1,0)) in front of a 'same' conv (models.py:345,388)
   // ---- weights (A stream) and biases
   const void* w = nullptr;
@@ -41,8 +44,8 @@ struct ConvArgs {
 };
 
 // Arguments of one fused ResBlock1 pair (modules.py:148-153):  y = x + conv2(lrelu(conv1(lrelu(x)))).
-// x / y are frame-major tensors in the operand type; with m32 set the result is instead accumulated
-// into the fp32 MRF mean (models.py:378-384):  m32 = (accum ? m32 : 0) + scale * y.
+// x / y are frame-major tensors in the operand type (the MRF mean of the three ResBlocks, models.py:378-384,
+// is taken by the consumer of the y tensors while it stages its input).
 struct PairArgs {
   const void* x = nullptr; int64_t bs = 0; int32_t T = 0, C = 0, CP = 0;
   const void* w1 = nullptr; const float* b1 = nullptr;
@@ -50,7 +53,6 @@ struct PairArgs {
   int32_t k = 1, dil = 1, KS = 1, nIt = 1;
   float slope = 0.1f;
   void* y = nullptr;
-  float* m32 = nullptr; float scale = 1.f; int32_t accum = 0;
 };
 
 // One fused WaveNet layer (modules.py:87-112): k-tap conv h->2h + conditioning + tanh*sigmoid gate, then the

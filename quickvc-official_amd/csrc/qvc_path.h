@@ -170,6 +170,15 @@ struct Path {
     }
   }
 
+  // input = MRF mean of stage i's ResBlock outputs (each ResBlock's final tensor sits in its `ra` buffer)
+  void mean_input(ConvArgs& a, size_t i) {
+    const int NB = P.cfg.n_resblocks;
+    a.x_kind = XK_OP_FM;
+    a.x = wsp<void>(W.ra[i][0]);
+    a.x2 = wsp<void>(W.ra[i][(size_t)(NB > 1 ? 1 : 0)]);
+    a.x3 = wsp<void>(W.ra[i][(size_t)(NB > 2 ? 2 : 0)]);
+  }
+
   // ---- generator trunk (models.py:372-390)
   void dec_trunk(const float* z, float* post_out) {
     const qvc_config& c = P.cfg;
@@ -192,7 +201,7 @@ struct Path {
       {   // lrelu(0.1) -> ConvTranspose1d as `s` polyphase filters
         ConvArgs a = args(st.up);
         if (i == 0) { a.x = wsp<void>(W.c0); a.x_kind = XK_OP_FM; }
-        else { a.x = wsp<float>(W.m[i - 1]); a.x_kind = XK_F32_FM; a.slope_in = 0.1f; }
+        else { mean_input(a, i - 1); a.slope_in = 0.1f; }
         a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in; a.T_in = t_in;
         a.Nq = (t_out - 1 + p) / s + 1; a.T_out = t_out;
         a.y16 = wsp<void>(W.u[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;   // raw, operand type
@@ -209,18 +218,17 @@ struct Path {
           be.branch(j);
           const ConvDesc& d1 = st.c1[(size_t)j * 3 + q];
           const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
-          void* dst = q == 0 ? wsp<void>(W.ra[i][(size_t)j]) : wsp<void>(W.rb[i][(size_t)j]);
+          // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
+          // consumer (next up-sampler / conv_post) while it stages its input, so nothing is accumulated here
+          void* dst = q == 1 ? wsp<void>(W.rb[i][(size_t)j]) : wsp<void>(W.ra[i][(size_t)j]);
           const bool last = q == 2;
-          const float scale = 1.f / (float)NB;
-          if (last && j > 0) be.wait_branch_done(j - 1);       // accumulate after the previous branch's mean update
           if (pair_supported(d1, d2)) {
             PairArgs pa;
             pa.x = src[(size_t)j]; pa.bs = bs; pa.T = t_out; pa.C = ch; pa.CP = d1.CinP;
             pa.w1 = blob + d1.w_off; pa.b1 = reinterpret_cast<const float*>(blob + d1.b_off);
             pa.w2 = blob + d2.w_off; pa.b2 = reinterpret_cast<const float*>(blob + d2.b_off);
             pa.k = d1.taps; pa.dil = d1.dil; pa.KS = d1.KS(); pa.nIt = d1.nIt(); pa.slope = 0.1f;
-            if (last) { pa.m32 = wsp<float>(W.m[i]); pa.scale = scale; pa.accum = j > 0 ? 1 : 0; }
-            else pa.y = dst;
+            pa.y = dst;
             if (status == QVC_OK) status = be.pair(d1, d2, pa, B, dtype());
           } else {
             void* xt = wsp<char>(W.xt[i]) + (size_t)j * (size_t)B * (size_t)bs * 2;
@@ -236,20 +244,20 @@ struct Path {
               a.x = xt; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
               a.Nq = t_out; a.T_out = t_out;
               a.res16 = src[(size_t)j]; a.res_bs = bs; a.res_ts = ch;
-              if (last) { a.y32 = wsp<float>(W.m[i]); a.y32_bs = bs; a.y32_ts = ch; a.y_scale = scale; a.y_accum = j > 0 ? 1 : 0; }
-              else { a.y16 = dst; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f; }
+              a.y16 = dst; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;
               conv(d2, a);
             }
           }
           if (last) be.branch_done(j);
           src[(size_t)j] = dst;
         }
-      be.join(NB);                                   // main stream continues after the last branch's mean update
+      be.join(NB);                                   // main stream continues when every branch is done
       t_in = t_out; ch_in = ch;
     }
     {   // lrelu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post(k7)
       ConvArgs a = args(P.conv_post);
-      a.x = wsp<float>(W.m[P.stages.size() - 1]); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in;
+      mean_input(a, P.stages.size() - 1);
+      a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in;
       a.T_in = t_in; a.slope_in = 0.01f; a.reflect = 1;
       a.Nq = t_in + 1; a.T_out = t_in + 1;
       a.y32 = post_out; a.y32_bs = (int64_t)(t_in + 1) * P.post_channels; a.y32_ts = P.post_channels;

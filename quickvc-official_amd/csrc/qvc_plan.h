@@ -163,7 +163,7 @@ inline int validate(const qvc_config& c) {
   if (bad(c.wn_kernel_size < 1 || c.wn_kernel_size % 2 == 0 || c.wn_kernel_size > 15)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.enc_layers < 1 || c.enc_layers > 64 || c.flow_layers < 1 || c.flow_layers > 64)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.n_flows < 1 || c.n_flows > 16 || c.n_flows % 2)) return QVC_ERR_BAD_CONFIG;   // flips must cancel
-  if (bad(c.n_ups < 1 || c.n_ups > QVC_MAX_UPS || c.n_resblocks < 1 || c.n_resblocks > QVC_MAX_RESBLOCKS)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.n_ups < 1 || c.n_ups > QVC_MAX_UPS || c.n_resblocks != 3)) return QVC_ERR_BAD_CONFIG;   // the MRF mean is taken over three ResBlocks
   int ch = c.upsample_initial_channel;
   if (bad(ch <= 0 || ch % 8)) return QVC_ERR_BAD_CONFIG;
   for (int i = 0; i < c.n_ups; ++i) {
@@ -293,7 +293,7 @@ struct Workspace {
   int64_t stats = 0;     // fp32 [B][T][2C]             enc_p.proj output
   int64_t z = 0;         // fp32 [B][T][C]              latent (flow state)
   int64_t c0 = 0;        // op   [B][T][init_ch]        lrelu(conv_pre + cond)
-  std::vector<int64_t> u, xt, m;           // per stage: up output, conv1 output (op type, unfused fallback); MRF mean (fp32)
+  std::vector<int64_t> u, xt;              // per stage: up output, conv1 output (op type, unfused fallback)
   std::vector<std::vector<int64_t>> ra, rb;   // per stage, per ResBlock: stream ping/pong (op type) -- ResBlocks may run concurrently
   int64_t post = 0;      // fp32 [B][F][post_channels]
   int64_t bytes = 0;
@@ -321,7 +321,6 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
     W.ra.emplace_back(); W.rb.emplace_back();
     for (int j = 0; j < c.n_resblocks; ++j) { W.ra.back().push_back(take(n * 2)); W.rb.back().push_back(take(n * 2)); }
     W.xt.push_back(take(n * 2 * c.n_resblocks));
-    W.m.push_back(take(n * 4));
   }
   W.post = take((int64_t)B * (t + 1) * P.post_channels * 4);
   W.bytes = off;

@@ -62,5 +62,5 @@ def emu_infer(model_config, sd, unit, g, noise, dtype="f16", taps=None):
         td = torch.float16 if dtype == "f16" else torch.bfloat16   # stage streams are carried in the operand type
         taps["ups0"] = ws[off:off + B * t1 * ch0 * 2].view(td).reshape(B, t1, ch0).float()
         off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 2)
-        taps["mrf0"] = ws[off:off + B * t1 * ch0 * 4].view(torch.float32).reshape(B, t1, ch0).clone()
+        taps["rb0"] = ws[off:off + B * t1 * ch0 * 2].view(td).reshape(B, t1, ch0).float()
     return out

@@ -69,6 +69,38 @@ int main(int argc, char** argv) {
     printf("%-14s MF%d WM%d NF%-2d chunks%d  %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d.MF, d.WM, nf, d.nchunk, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
+  {  // ---- polyphase up-samplers, conv_pre (weight-heavy, few frames)
+    struct U { const char* name; int Cin, Cout, T, k, s, p; int kind; };
+    std::vector<U> us = {{"ups0 512>256 s5", 512, 256, 250, 16, 5, 6, 0}, {"ups1 256>128 s4", 256, 128, 1250, 16, 4, 6, 1}};
+    for (const U& u : us) {
+      ConvDesc d = make_upconv(u.Cin, u.Cout, u.k, u.s, u.p);
+      d.w_off = 0; d.b_off = align_up(d.w_bytes(), 256);
+      size_t wb = d.b_off + d.b_bytes();
+      std::vector<char> hw(wb);
+      std::vector<float> w((size_t)d.M * d.Cin * d.taps), bias(d.M, 0.01f);
+      for (size_t i = 0; i < w.size(); ++i) w[i] = ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.02f;
+      pack_plain_conv(d, w.data(), bias.data(), QVC_F16, hw.data());
+      void* dw; CK(hipMalloc(&dw, wb)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
+      ConvArgs a;
+      a.w = dw; a.bias = (const float*)((char*)dw + d.b_off);
+      const int t_out = u.T * u.s;
+      a.T_in = u.T; a.Nq = (t_out - 1 + u.p) / u.s + 1; a.T_out = t_out;
+      if (u.kind == 0) { a.x = x16; a.x_kind = XK_OP_FM; } else { a.x = x32; a.x_kind = XK_F32_FM; a.slope_in = 0.1f; }
+      a.x_bs = (int64_t)u.T * u.Cin; a.x_ts = u.Cin;
+      a.y16 = y16; a.y16_bs = (int64_t)t_out * u.Cout; a.y16_ts = u.Cout;
+      int nf = 0;
+      for (int i = 0; i < 3; ++i) if (launch_conv(d, a, B, EPI_STD, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch failed\n", u.name); break; }
+      CK(hipStreamSynchronize(st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i) launch_conv(d, a, B, EPI_STD, QVC_F16, st, &nf);
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us_ = ms * 1e3 / reps;
+      const double flops = 2.0 * B * u.T * (double)u.Cin * u.Cout * u.k;
+      printf("%-16s MF%d WM%d NF%-2d chunks%d %8.1f us  %7.1f TF\n", u.name, d.MF, d.WM, nf, d.nchunk, us_, flops / us_ * 1e-6);
+      CK(hipFree(dw));
+    }
+  }
   {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
     const int H = 192, T = 250, L = 16;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
