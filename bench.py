@@ -59,11 +59,18 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal switch for a 1-GPU box (never set by the driver): QVC_BENCH_REHEARSAL=1 puts every rank on
+    # cuda:0 and uses gloo, to exercise the multi-rank control flow without a second GPU.
+    rehearsal = os.environ.get("QVC_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg = dict(q.DEFAULT_MODEL_CONFIG)
     model = q.SynthesizerTrn(641, 32, **cfg, operand_dtype=args.dtype)
