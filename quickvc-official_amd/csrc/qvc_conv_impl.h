@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       const frag* ap = static_cast<const frag*>(a.w_in[l]) + ((size_t)wm * a.nIt1 * MF) * 64 + lane;
-      gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, 0);
+      if (!QVC_ABL(1)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, 0);
       const float* bb = a.bbias + (size_t)b * a.bbias_bs + (size_t)l * 2 * a.H;
 #pragma unroll
       for (int f = 0; f < FW; ++f) {
@@ -814,7 +814,9 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
           const int j = n * 16 + lrow;
           const f32x4 t = acc[f][n], sg = acc[FW + f][n];
           quad o;
-          if (ch0 < a.H) {
+          if (ch0 < a.H && QVC_ABL(4)) {
+            o[0] = O::cvt(t[0] + bt.x); o[1] = O::cvt(t[1] + bt.y); o[2] = O::cvt(sg[2] + bs.z); o[3] = O::cvt(sg[3] + bs.w);
+          } else if (ch0 < a.H) {
             o[0] = O::cvt(fast_tanh(t[0] + bt.x) * fast_sigmoid(sg[0] + bs.x));
             o[1] = O::cvt(fast_tanh(t[1] + bt.y) * fast_sigmoid(sg[1] + bs.y));
             o[2] = O::cvt(fast_tanh(t[2] + bt.z) * fast_sigmoid(sg[2] + bs.z));
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
       const float* brs = a.b_rs[l];
       if (!last) {
         const frag* ap = static_cast<const frag*>(a.w_rs[l]) + ((size_t)wm * a.KS * MF) * 64 + lane;
-        gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+        if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
 #pragma unroll
         for (int f = 0; f < FW; ++f) {
           const int ch0 = (wm * FW + f) * 16 + lq * 4;

@@ -126,6 +126,32 @@ int main(int argc, char** argv) {
     printf("%-14s FW%d NF%-2d               %8.1f us/layer  %7.1f TF  (%.1f%% of 2.5PF)\n", "wn layer x16", din.MF / 2, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
+  {  // ---- whole-stack WaveNet launches: 4 layers per launch, 8 distinct weight sets (cold weights)
+    const int H = 192, T = 250, L = 4, SETS = 8;
+    ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
+    din.w_off = 0; drs.w_off = align_up(din.w_bytes(), 256); drs.b_off = drs.w_off + align_up(drs.w_bytes(), 256);
+    const size_t per = drs.b_off + align_up(drs.b_bytes(), 256);
+    std::vector<char> hw(per * L * SETS, 0);
+    for (size_t i = 0; i < hw.size(); i += 2) { hw[i] = (char)((i * 131) & 0x7f); hw[i + 1] = (char)(0x20 + ((i >> 3) & 7)); }
+    void* dw; CK(hipMalloc(&dw, hw.size())); CK(hipMemcpy(dw, hw.data(), hw.size(), hipMemcpyHostToDevice));
+    auto run = [&]() {
+      for (int sset = 0; sset < SETS; ++sset) {
+        WnStackArgs a; a.x0 = x32; a.out = y32; a.bs = (int64_t)T * H; a.T = T; a.H = H; a.HP = din.CinP;
+        for (int l = 0; l < L; ++l) { char* base = (char*)dw + per * (sset * L + l);
+          a.w_in[l] = base; a.w_rs[l] = base + drs.w_off; a.b_rs[l] = (const float*)(base + drs.b_off); }
+        a.bbias = bb; a.bbias_bs = 0; a.layers = L; a.taps = 5; a.KS = din.KS(); a.nIt1 = din.nIt(); a.final_layer = 0; a.x_out = res;
+        launch_wn_stack(din, a, B, QVC_F16, st);
+      } };
+    run(); CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) run();
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps / (SETS * L);
+    const double flops = 2.0 * B * T * (double)H * (2.0 * H * 5 + 2.0 * H);
+    printf("%-14s FW3 L4                 %8.1f us/layer  %7.1f TF\n", "wn stack", us, flops / us * 1e-6);
+    CK(hipFree(dw));
+  }
   // ---- fused ResBlock pairs
   struct PShape { const char* name; int C, T, k, dil; int force_mf, force_wm; };
   std::vector<PShape> pshapes = {{"pair s2 k3 d1", 128, 5000, 3, 1}, {"pair s2 k7 d3", 128, 5000, 7, 3}, {"pair s2 k11 d5", 128, 5000, 11, 5},
