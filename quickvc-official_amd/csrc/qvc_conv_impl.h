@@ -421,13 +421,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // from there, and the epilogue adds the raw residual and stores the operand-type result.  Compared with two launches this removes the
 // intermediate's HBM round trip and one staging pass; the price is NF+1 instead of NF column
 // fragments in GEMM1.  The residual stream is carried in the operand type (costs 0.35 dB).
-template <typename T, int MF, int NF, int WM>
-__global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
+// NWV = waves per workgroup (4, or 8 with all of them along M: see wide_pair_layout in qvc_plan.h)
+template <typename T, int MF, int NF, int WM, int NWV>
+__global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
   using quad = typename O::quad;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WN = kWaves / WM;
+  constexpr int WN = NWV / WM;
+  constexpr int NTHR = NWV * 64;
   constexpr int NF1 = NF + 1;
   constexpr int NT = WN * NF * 16;       // output frames per block
   constexpr int N1P = WN * NF1 * 16;     // intermediate frames computed per block (>= NT + 2*h2)
@@ -450,12 +452,12 @@ __global__ __launch_bounds__(256) void rbpair_kernel(const PairArgs a) {
     const int t_base = q0 - h2 - h1;
     const int total = Rx * cpr;
     constexpr int kU = 8;
-    for (int base = tid; base < total; base += 256 * kU) {
+    for (int base = tid; base < total; base += NTHR * kU) {
       uint4 v[kU];
       int dst[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const int idx = base + u * 256;
+        const int idx = base + u * NTHR;
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
         const bool ok = idx < total && ti >= 0 && ti < a.T && (c8 * 8 < a.C);
@@ -1025,6 +1027,7 @@ int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, 
       default: return QVC_ERR_BAD_CONFIG;
     }
   }
+  if (d.WM > kWaves) return QVC_ERR_BAD_CONFIG;            // 8-wave layouts exist for the fused pair kernel only
   switch (d.WM * 10 + d.MF) {
     case 41: return launch_nf<T, 1, 4, EPI_STD>(d, a, batch, stream, nf_out);
     case 42: return launch_nf<T, 2, 4, EPI_STD>(d, a, batch, stream, nf_out);
@@ -1040,7 +1043,8 @@ int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, 
 // ---- fused pair: tile choice + dispatch
 inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
   static const int nfs[] = {2, 4, 5, 8, 10}; // measured at B=32, MF 4: NF 5 (2 workgroups/CU) beats 4 and 8 by 7-35 %
-  const int WN = kWaves / d.WM;
+  const int NWV = block_waves(d);
+  const int WN = NWV / d.WM;
   const int halo1 = (d.taps - 1) * d.dil, rowbytes = d.CinP * 2;
   TileChoice best{0, 0, 0};
   double best_cost = 1e300;
@@ -1050,41 +1054,42 @@ inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
     if (lds > 160 * 1024) continue;
     const int NT = WN * NF * 16;
     const long blocks = (long)ceil_div(T, NT) * batch;
-    const int bpc = (int)std::min<size_t>(2, (160 * 1024) / lds);           // blocks that can share a CU
+    // workgroups that can share a CU: 2 x 4 waves or 1 x 8 waves (two waves per SIMD either way)
+    const int bpc = NWV == 8 ? 1 : (int)std::min<size_t>(2, (160 * 1024) / lds);
     const long rounds = (blocks + 256L * bpc - 1) / (256L * bpc);
-    // per-block work in frame units: both GEMMs + staging/epilogue; one block per CU cannot overlap
-    // its memory phases with another block's MFMA phases
+    // per-workgroup work in frame units: both GEMMs + staging/epilogue; a single 4-wave workgroup per CU
+    // cannot overlap its memory phases with another one's MFMA phases
     const double work = WN * (NF + 1) * 16 + NT + 0.35 * halo1 + 32.0;
-    const double cost = rounds * bpc * work * (bpc == 1 ? 1.3 : 1.0);
+    const double cost = rounds * bpc * work * ((bpc == 1 && NWV == 4) ? 1.3 : 1.0);
     if (cost < best_cost) { best_cost = cost; best = TileChoice{NF, (int)blocks, lds}; }
   }
   return best;
 }
 
-template <typename T, int MF, int NF, int WM>
+template <typename T, int MF, int NF, int WM, int NWV>
 inline int launch_pair_one(const PairArgs& a, int batch, size_t lds, hipStream_t stream) {
-  auto kern = rbpair_kernel<T, MF, NF, WM>;
+  auto kern = rbpair_kernel<T, MF, NF, WM, NWV>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return QVC_ERR_LAUNCH;
     attr_done = true;
   }
-  constexpr int NT = (kWaves / WM) * NF * 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, NT), (unsigned)batch), dim3(256), lds, stream, a);
+  constexpr int NT = (NWV / WM) * NF * 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, NT), (unsigned)batch), dim3(NWV * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
-template <typename T, int MF, int WM>
+template <typename T, int MF, int WM, int NWV>
 inline int launch_pair_nf(const ConvDesc& d, const PairArgs& a, int batch, hipStream_t stream, int* nf_out) {
   const TileChoice tc = choose_pair_tile(d, a.T, batch);
   if (nf_out) *nf_out = tc.NF;
   switch (tc.NF) {
-    case 2: return launch_pair_one<T, MF, 2, WM>(a, batch, tc.lds, stream);
-    case 4: return launch_pair_one<T, MF, 4, WM>(a, batch, tc.lds, stream);
-    case 5: return launch_pair_one<T, MF, 5, WM>(a, batch, tc.lds, stream);
-    case 8: if constexpr (MF * 9 * 4 <= 160) return launch_pair_one<T, MF, 8, WM>(a, batch, tc.lds, stream); break;
-    case 10: if constexpr (MF * 11 * 4 <= 96) return launch_pair_one<T, MF, 10, WM>(a, batch, tc.lds, stream); break;
+    case 2: return launch_pair_one<T, MF, 2, WM, NWV>(a, batch, tc.lds, stream);
+    case 4: return launch_pair_one<T, MF, 4, WM, NWV>(a, batch, tc.lds, stream);
+    case 5: return launch_pair_one<T, MF, 5, WM, NWV>(a, batch, tc.lds, stream);
+    case 8: if constexpr (MF * 9 * 4 <= 160) return launch_pair_one<T, MF, 8, WM, NWV>(a, batch, tc.lds, stream); break;
+    case 10: if constexpr (MF * 11 * 4 <= 96) return launch_pair_one<T, MF, 10, WM, NWV>(a, batch, tc.lds, stream); break;
     default: break;
   }
   return QVC_ERR_BAD_CONFIG;
@@ -1094,13 +1099,16 @@ template <typename T>
 int launch_pair_typed(const ConvDesc& d, const PairArgs& a, int batch, void* stream_v, int* nf_out) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   switch (d.WM * 10 + d.MF) {
-    case 41: return launch_pair_nf<T, 1, 4>(d, a, batch, stream, nf_out);
-    case 42: return launch_pair_nf<T, 2, 4>(d, a, batch, stream, nf_out);
-    case 43: return launch_pair_nf<T, 3, 4>(d, a, batch, stream, nf_out);
-    case 44: return launch_pair_nf<T, 4, 4>(d, a, batch, stream, nf_out);
-    case 23: return launch_pair_nf<T, 3, 2>(d, a, batch, stream, nf_out);
-    case 24: return launch_pair_nf<T, 4, 2>(d, a, batch, stream, nf_out);
-    case 14: return launch_pair_nf<T, 4, 1>(d, a, batch, stream, nf_out);
+    case 41: return launch_pair_nf<T, 1, 4, 4>(d, a, batch, stream, nf_out);
+    case 42: return launch_pair_nf<T, 2, 4, 4>(d, a, batch, stream, nf_out);
+    case 43: return launch_pair_nf<T, 3, 4, 4>(d, a, batch, stream, nf_out);
+    case 44: return launch_pair_nf<T, 4, 4, 4>(d, a, batch, stream, nf_out);
+    case 23: return launch_pair_nf<T, 3, 2, 4>(d, a, batch, stream, nf_out);
+    case 24: return launch_pair_nf<T, 4, 2, 4>(d, a, batch, stream, nf_out);
+    case 14: return launch_pair_nf<T, 4, 1, 4>(d, a, batch, stream, nf_out);
+    case 82: return launch_pair_nf<T, 2, 8, 8>(d, a, batch, stream, nf_out);
+    case 83: return launch_pair_nf<T, 3, 8, 8>(d, a, batch, stream, nf_out);
+    case 84: return launch_pair_nf<T, 4, 8, 8>(d, a, batch, stream, nf_out);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }

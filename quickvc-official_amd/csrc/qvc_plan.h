@@ -86,13 +86,26 @@ inline void choose_mf(ConvDesc& d) {
   d.nchunk = ceil_div(d.M, d.WM * d.MF * 16);
 }
 
+// Waves of the workgroup that runs a conv: 4, or 8 (all along M) for the wide ResBlock-pair layout.
+inline int block_waves(const ConvDesc& d) { return d.WM > kWaves ? d.WM : kWaves; }
+
 // Can the two convs of a ResBlock1 pair run as one fused launch?  (one workgroup must own all channels)
 inline bool pair_supported(const ConvDesc& d1, const ConvDesc& d2) {
   if (d1.nchunk != 1 || d2.nchunk != 1 || d1.MF != d2.MF || d1.WM != d2.WM) return false;
   if (d1.M != d2.M || d1.Cin != d1.M || d2.Cin != d2.M || d1.taps != d2.taps || d2.dil != 1 || d1.up_s != 1 || d2.up_s != 1) return false;
   if (d1.MF * 3 * 4 > 160) return false;
-  const int64_t lds = (int64_t)((kWaves / d1.WM) * 3 * 16 + (d1.taps - 1) * d1.dil) * d1.CinP * 2;   // smallest tile
+  const int64_t lds = (int64_t)((block_waves(d1) / d1.WM) * 3 * 16 + (d1.taps - 1) * d1.dil) * d1.CinP * 2;   // smallest tile
   return lds <= 160 * 1024;
+}
+
+// ResBlock convs with >= 256 channels: 8 waves, all along M, 2..4 fragments each.  Two 4-wave workgroups per CU
+// would each stream the pair's full weights (2 x 1.44 MB at 256 channels, k 11), and weight delivery into the CU
+// (~70 GB/s) is what bounds those launches; one 8-wave workgroup with twice the frames halves that traffic.
+inline void wide_pair_layout(ConvDesc& d1, ConvDesc& d2) {
+  if (d1.M < 256 || d1.M % 128 || d1.M / 128 > 4) return;
+  ConvDesc a = d1, b = d2;
+  a.WM = b.WM = 8; a.MF = b.MF = d1.M / 128; a.nchunk = b.nchunk = 1;
+  if (pair_supported(a, b)) { d1 = a; d2 = b; }
 }
 
 // Whole-stack WaveNet kernel: window = 32 output frames + halo, built for 3 or 6 column fragments.
@@ -266,8 +279,10 @@ inline Plan build_plan(const qvc_config& c) {
     ch /= 2; st.ch = ch; st.rate = s; P.total_up *= s;
     for (int j = 0; j < c.n_resblocks; ++j)
       for (int q = 0; q < 3; ++q) {
-        ConvDesc a = make_conv(ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilations[j][q]); place(a);
-        ConvDesc b = make_conv(ch, ch, c.resblock_kernel_sizes[j], 1); place(b);
+        ConvDesc a = make_conv(ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilations[j][q]);
+        ConvDesc b = make_conv(ch, ch, c.resblock_kernel_sizes[j], 1);
+        wide_pair_layout(a, b);
+        place(a); place(b);
         st.c1.push_back(a); st.c2.push_back(b);
       }
     P.stages.push_back(st);

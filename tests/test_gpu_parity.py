@@ -271,14 +271,14 @@ def test_chunked_streaming_is_exact(lib, dev):
 
 
 def test_wide_config_takes_the_fallback_paths(lib, dev):
-    """A config the fused kernels do not cover: stage-1 ResBlocks 384 channels wide (two M chunks -> the
+    """A config the fused kernels do not cover: stage-1 ResBlocks 416 channels wide (two M chunks -> the
     conv1 / conv2 launches with an operand-type residual instead of the fused pair), WaveNet width 256
     (4 fragments per wave -> per-layer kernel, coupling pre/post as separate launches).  Checked against
     the CPU oracle only (no golden: the reference was not run on this config)."""
     import quickvc_official_amd as q
     from quickvc_official_amd.engine import QvcEngine
     from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_inputs
-    cfg = dict(q.DEFAULT_MODEL_CONFIG, inter_channels=64, hidden_channels=256, upsample_initial_channel=768, gin_channels=32)
+    cfg = dict(q.DEFAULT_MODEL_CONFIG, inter_channels=64, hidden_channels=256, upsample_initial_channel=832, gin_channels=32)
     model = q.SynthesizerTrn(641, 32, **cfg)
     sd = make_synthetic_state_dict(model, 77)
     unit, g, noise = make_synthetic_inputs(2, 20, 256, 64, 32, seed0=5)
@@ -287,7 +287,7 @@ def test_wide_config_takes_the_fallback_paths(lib, dev):
     out, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
     torch.cuda.synchronize()
     names = [r["name"] for r in recs]
-    assert sum(n.startswith("rbpair<") for n in names) == 9           # stage 2 (192 channels) still fuses
+    assert sum(n.startswith("rbpair<") for n in names) == 9           # stage 2 (208 channels) still fuses
     assert sum(n.startswith("wn_layer<f16,FW4") for n in names) == 32
     assert sum(n.startswith("conv<") for n in names) == 2 + 8 + 1 + 2 + 1 + 18   # + 9 x (conv1, conv2) of stage 1
     for b in range(2):

@@ -26,7 +26,7 @@ def load(d, counter):
 
 
 def pretty(name):
-    m = re.search(r"rbpair_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", name)
+    m = re.search(r"rbpair_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi\d+E", name)
     if m:
         return f"rbpair<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)}>"
     m = re.search(r"conv_mfma_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
