@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 1
+#define QVC_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -90,7 +90,7 @@ typedef struct qvc_config {
   int32_t decoder;                  /* QVC_DEC_*                                         */
   int32_t fir_taps;                 /* 63: multistream_conv_post / PQMF taps+1           */
   int32_t operand_dtype;            /* QVC_BF16 / QVC_F16                                */
-  int32_t reserved0;                /* must be 0                                          */
+  int32_t n_mel_channels;           /* SpeakerEncoder input size (models.py:508); 0 = 80  */
 } qvc_config;
 
 /* One named fp32 tensor of the reference checkpoint's state_dict (utils.py:183-193). */
@@ -201,6 +201,25 @@ int qvc_conv1d(const float* x, const float* w_host, const float* bias_host, floa
                int32_t k, int32_t dilation, float slope_in, int32_t operand_dtype,
                void* w_scratch_host, void* w_scratch_dev, int64_t scratch_bytes,
                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- speaker encoder: replaces SpeakerEncoder.embed_utterance (models.py:507-546) -------
+ * The step of SynthesizerTrn.infer in front of the path (models.py:635):
+ * 3-layer LSTM n_mel -> gin over 128-frame partials at hop 64 (plus the last 128 frames),
+ * Linear + ReLU + L2 normalisation per partial, mean over the partials (not re-normalised).
+ * All partials of all utterances run in one persistent-recurrence launch per layer.
+ *   mel (U, n_mel, mel_frames) fp32 -- the layout convert.py:77 hands to infer()
+ *   g   (U, gin_channels)     fp32
+ * Own blob (state-dict keys enc_spk.lstm.{weight,bias}_{ih,hh}_l{0,1,2}, enc_spk.linear.*),
+ * so a host may pack it only when it embeds speakers.  Needs gin_channels % 8 == 0 and
+ * gin_channels <= 256 (QVC_ERR_BAD_CONFIG otherwise).
+ */
+int64_t qvc_spk_blob_bytes(const qvc_config* cfg);
+int qvc_spk_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors, int32_t n_tensors,
+                         void* blob_host, int64_t blob_bytes);
+int64_t qvc_spk_workspace_bytes(const qvc_config* cfg, int32_t utterances, int32_t mel_frames);
+int qvc_speaker_embed(const qvc_config* cfg, const void* spk_blob_dev, const float* mel, float* g,
+                      int32_t utterances, int32_t mel_frames,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -354,6 +354,70 @@ struct EmuBackend {
     return QVC_OK;
   }
   int zero(void* p, size_t bytes) { std::memset(p, 0, bytes); return QVC_OK; }
+
+  // ---- speaker encoder launches (csrc/qvc_spk.hip): W_hh recovered from its fragment stream with the kernel's
+  //      index math; h rounded to the operand type between steps as the LDS copy is; cell state in fp32
+  int lstm(const LstmArgs& a, int KS, int dtype) {
+    const int H = a.H, HP = KS * 32, NW = KS;
+    std::vector<float> W((size_t)4 * H * HP, 0.f);
+    const uint16_t* src = static_cast<const uint16_t*>(a.w_hh);
+    SpkPlan S; S.H = H; S.HP = HP; S.NW = NW; S.KS = KS;
+    for (int w = 0; w < NW; ++w)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int f = 0; f < 8; ++f)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int row = spk_hh_row(S, w, f, lane & 15);
+            for (int j = 0; j < 8; ++j) {
+              const uint16_t h = src[((((size_t)w * KS + ks) * 8 + f) * 64 + lane) * 8 + j];
+              if (row >= 0) W[(size_t)row * HP + ks * 32 + (lane >> 4) * 8 + j] = dtype == QVC_F16 ? from_f16(h) : from_bf16(h);
+            }
+          }
+    auto sig = [](float x) { return 1.f / (1.f + std::exp(-x)); };
+    for (int p = 0; p < a.P; ++p) {
+      const float* xb;
+      if (a.shared) {
+        const int u = p / a.n_part, i = p % a.n_part;
+        xb = a.xp + ((size_t)u * a.F + spk_start(a.F, i)) * 4 * H;
+      } else {
+        xb = a.xp + (size_t)p * a.S * 4 * H;
+      }
+      std::vector<float> h((size_t)HP, 0.f), c((size_t)H, 0.f), hn((size_t)H, 0.f), gate((size_t)4 * H);
+      for (int t = 0; t < a.S; ++t) {
+        for (int r = 0; r < 4 * H; ++r) {
+          double acc = xb[(size_t)t * 4 * H + r];
+          for (int k = 0; k < H; ++k) acc += (double)W[(size_t)r * HP + k] * h[k];
+          gate[r] = (float)acc;
+        }
+        for (int j = 0; j < H; ++j) {
+          c[j] = sig(gate[H + j]) * c[j] + sig(gate[j]) * std::tanh(gate[2 * H + j]);
+          hn[j] = sig(gate[3 * H + j]) * std::tanh(c[j]);
+          h[j] = round_op(hn[j], dtype);
+          if (a.hseq) static_cast<uint16_t*>(a.hseq)[((size_t)p * a.S + t) * H + j] = dtype == QVC_F16 ? to_f16(h[j]) : to_bf16(h[j]);
+        }
+      }
+      if (a.hfin) std::memcpy(a.hfin + (size_t)p * H, hn.data(), (size_t)H * 4);
+    }
+    return QVC_OK;
+  }
+  int spk_embed(const SpkEmbedArgs& a) {
+    const int H = a.H;
+    for (int u = 0; u < a.utterances; ++u) {
+      std::vector<double> mean((size_t)H, 0.0);
+      for (int i = 0; i < a.n_part; ++i) {
+        const float* h = a.hfin + ((size_t)u * a.n_part + i) * H;
+        std::vector<double> e((size_t)H);
+        double ss = 0.0;
+        for (int r = 0; r < H; ++r) {
+          double s = a.lb[r];
+          for (int k = 0; k < H; ++k) s += (double)a.lw[(size_t)r * H + k] * h[k];
+          e[r] = s > 0.0 ? s : 0.0; ss += e[r] * e[r];
+        }
+        for (int r = 0; r < H; ++r) mean[r] += e[r] / std::sqrt(ss);
+      }
+      for (int r = 0; r < H; ++r) a.g[(size_t)u * H + r] = (float)(mean[r] / a.n_part);
+    }
+    return QVC_OK;
+  }
 };
 
 struct Run {
@@ -383,6 +447,18 @@ int qvc_emu_infer_batch(const qvc_config* cfg, const void* blob, const float* un
   c.dec_trunk(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post));
   c.tail(c.wsp<float>(r.W.post), out, nullptr, frames * r.P.total_up + 1);
   return c.status;
+}
+
+// Same signature as qvc_speaker_embed, host pointers, no stream.
+int qvc_emu_speaker_embed(const qvc_config* cfg, const void* spk_blob, const float* mel, float* g, int32_t utterances,
+                          int32_t mel_frames, void* workspace, int64_t workspace_bytes) {
+  SpkPlan S = build_spk_plan(*cfg);
+  if (S.status != QVC_OK) return S.status;
+  const SpkWorkspace W = carve_spk_workspace(S, utterances, mel_frames);
+  if (workspace_bytes < W.bytes) return QVC_ERR_SMALL_BUFFER;
+  EmuBackend be;
+  return spk_path(S, cfg->operand_dtype, static_cast<const char*>(spk_blob), static_cast<char*>(workspace), W, mel, g,
+                  utterances, mel_frames, be);
 }
 
 // Stage taps for debugging: copies frame-major fp32 buffers out of the workspace after a run.

@@ -98,7 +98,7 @@ def main(argv=None) -> None:
                 wav = trim(load_wav(tgt, d.sampling_rate), top_db=20)
                 mel = wave_to_mel(torch.from_numpy(wav).unsqueeze(0).cuda(), d.filter_length, d.n_mel_channels,
                                   d.sampling_rate, d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
-                g_cache[tgt] = net_g.enc_spk.embed_utterance(mel.transpose(1, 2))
+                g_cache[tgt] = net_g.speaker_embed(mel)                 # (1, 80, F') -> (1, gin), HIP LSTM
             prepared.append((title, _load_units(src), g_cache[tgt]))
         # this rank's shard of the list, then equal-length utterances share a launch
         mine = shard_indices(len(prepared), rank, world, [p[1].shape[-1] for p in prepared])

@@ -109,6 +109,22 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
   int32_t batch, F;
 };
 
+// One LSTM layer's recurrence over all partials (models.py:510,516): gates = xp[t] + W_hh h[t-1], PyTorch gate
+// order i,f,g,o.  The input projection xp (with b_ih + b_hh) comes from a conv launch.
+struct LstmArgs {
+  const float* xp;      // fp32, 4H per frame
+  int32_t shared;       // 1: xp is [U][F][4H], partial p reads frames spk_start(p)+t; 0: xp is [P][S][4H]
+  int32_t F, n_part, S, P, H;
+  const void* w_hh;     // [wave][k-step][8 fragments][64 lanes][8], see spk_hh_row
+  void* hseq;           // [P][S][H] operand type: input of the next layer (null on the last layer)
+  float* hfin;          // [P][H] fp32: h after the last step (last layer only)
+};
+
+struct SpkEmbedArgs {   // relu(linear(h)) / ||.||, mean over an utterance's partials (models.py:514-518,539)
+  const float* hfin; const float* lw; const float* lb; float* g;
+  int32_t utterances, n_part, H;
+};
+
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);

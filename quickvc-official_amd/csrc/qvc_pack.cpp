@@ -282,3 +282,70 @@ extern "C" int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors
   }
   return pk.status;
 }
+
+// ---------------------------------------------------------------- speaker encoder blob (models.py:507-518)
+extern "C" int64_t qvc_spk_blob_bytes(const qvc_config* cfg) {
+  if (!cfg) return QVC_ERR_BAD_ARG;
+  SpkPlan S = build_spk_plan(*cfg);
+  return S.status == QVC_OK ? S.blob_bytes : (int64_t)S.status;
+}
+
+extern "C" int qvc_spk_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors, int32_t n_tensors,
+                                    void* blob_host, int64_t blob_bytes) {
+  if (!cfg || !tensors || n_tensors <= 0 || !blob_host) return QVC_ERR_BAD_ARG;
+  SpkPlan S = build_spk_plan(*cfg);
+  if (S.status != QVC_OK) return S.status;
+  if (blob_bytes < S.blob_bytes) return QVC_ERR_SMALL_BUFFER;
+  std::memset(blob_host, 0, (size_t)S.blob_bytes);
+  Packer pk{*cfg, {}, static_cast<char*>(blob_host)};
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!tensors[i].name || !tensors[i].data || tensors[i].ndim < 0 || tensors[i].ndim > 4) return QVC_ERR_BAD_ARG;
+    pk.tensors[tensors[i].name] = &tensors[i];
+  }
+  auto matrix = [&](const std::string& name, int64_t rows, int64_t cols) -> const float* {
+    const qvc_tensor* t = pk.find(name);
+    if (!t) return nullptr;
+    if (t->ndim != 2 || t->shape[0] != rows || t->shape[1] != cols) {
+      if (pk.status == QVC_OK) { pk.status = QVC_ERR_BAD_SHAPE; pk.missing = name; }
+      return nullptr;
+    }
+    return t->data;
+  };
+  auto vec = [&](const std::string& name, int64_t n) -> const float* {
+    const qvc_tensor* t = pk.find(name);
+    if (!t) return nullptr;
+    if (Packer::numel(t) != n) { if (pk.status == QVC_OK) { pk.status = QVC_ERR_BAD_SHAPE; pk.missing = name; } return nullptr; }
+    return t->data;
+  };
+  const int H = S.H;
+  for (int l = 0; l < kSpkLayers; ++l) {
+    const std::string sfx = "_l" + std::to_string(l);
+    const int cin = l == 0 ? S.n_mel : H;
+    const float* wih = matrix("enc_spk.lstm.weight_ih" + sfx, 4 * H, cin);
+    const float* whh = matrix("enc_spk.lstm.weight_hh" + sfx, 4 * H, H);
+    const float* bih = vec("enc_spk.lstm.bias_ih" + sfx, 4 * H);
+    const float* bhh = vec("enc_spk.lstm.bias_hh" + sfx, 4 * H);
+    if (pk.status != QVC_OK) return pk.status;
+    // input projection with both biases folded (torch.nn.LSTM adds b_ih + b_hh to every gate pre-activation)
+    pk.pack(S.ih[l], [&](int v, int, int ci) { return wih[(size_t)v * cin + ci]; },
+            [&](int v) { return bih[v] + bhh[v]; });
+    // recurrent weights: [wave][k-step][fragment 2*gate+half][lane][8]
+    uint16_t* dst = reinterpret_cast<uint16_t*>(pk.blob + S.hh_off[l]);
+    for (int w = 0; w < S.NW; ++w)
+      for (int ks = 0; ks < S.KS; ++ks)
+        for (int f = 0; f < 8; ++f)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int row = spk_hh_row(S, w, f, lane & 15);
+            for (int j = 0; j < 8; ++j) {
+              const int k = ks * kKStep + (lane >> 4) * 8 + j;
+              *dst++ = pk.cvt(row >= 0 && k < H ? whh[(size_t)row * H + k] : 0.f);
+            }
+          }
+  }
+  const float* lw = matrix("enc_spk.linear.weight", H, H);
+  const float* lb = vec("enc_spk.linear.bias", H);
+  if (pk.status != QVC_OK) return pk.status;
+  std::memcpy(pk.blob + S.lin_w_off, lw, (size_t)H * H * 4);
+  std::memcpy(pk.blob + S.lin_b_off, lb, (size_t)H * 4);
+  return QVC_OK;
+}

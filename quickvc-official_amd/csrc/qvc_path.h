@@ -272,4 +272,46 @@ struct Path {
   }
 };
 
+// ---- speaker encoder (models.py:507-546): per layer one conv launch (input projection of all frames) and one
+// persistent recurrence launch, then the embedding head.  Backend adds:  int lstm(const LstmArgs&, int KS, int dtype);
+//                                                                        int spk_embed(const SpkEmbedArgs&);
+template <class Backend>
+int spk_path(const SpkPlan& S, int dtype, const char* blob, char* ws, const SpkWorkspace& W, const float* mel, float* g,
+             int U, int F, Backend& be) {
+  const int H = S.H, n_part = spk_partials(F), St = spk_steps(F), P = U * n_part;
+  for (int l = 0; l < kSpkLayers; ++l) {
+    const ConvDesc& d = S.ih[l];
+    ConvArgs ca;
+    ca.w = blob + d.w_off; ca.bias = reinterpret_cast<const float*>(blob + d.b_off);
+    ca.Cin = d.Cin; ca.CinP = d.CinP; ca.taps = 1; ca.dil = 1; ca.left = 0;
+    ca.KS = d.KS(); ca.nIt = d.nIt(); ca.nchunk = d.nchunk; ca.M = d.M; ca.up_s = 1; ca.up_p = 0; ca.Cout = d.Cout;
+    int batch;
+    if (l == 0) {     // mel (U, n_mel, F) as handed to infer() (convert.py:77); the transpose of models.py:635 is the staging
+      ca.x = mel; ca.x_kind = XK_F32_CM; ca.x_bs = (int64_t)S.n_mel * F; ca.x_ts = F; ca.T_in = F;
+      ca.Nq = F; ca.T_out = F;
+      ca.y32 = reinterpret_cast<float*>(ws + W.xp0); ca.y32_bs = (int64_t)F * 4 * H; ca.y32_ts = 4 * H;
+      batch = U;
+    } else {
+      ca.x = ws + W.hseq; ca.x_kind = XK_OP_FM; ca.x_bs = (int64_t)St * H; ca.x_ts = H; ca.T_in = St;
+      ca.Nq = St; ca.T_out = St;
+      ca.y32 = reinterpret_cast<float*>(ws + W.xp); ca.y32_bs = (int64_t)St * 4 * H; ca.y32_ts = 4 * H;
+      batch = P;
+    }
+    int rc = be.conv(d, ca, batch, EPI_STD, dtype);
+    if (rc != QVC_OK) return rc;
+    LstmArgs la;
+    la.xp = reinterpret_cast<const float*>(ws + (l == 0 ? W.xp0 : W.xp));
+    la.shared = l == 0 ? 1 : 0;
+    la.F = F; la.n_part = n_part; la.S = St; la.P = P; la.H = H;
+    la.w_hh = blob + S.hh_off[l];
+    la.hseq = l + 1 < kSpkLayers ? ws + W.hseq : nullptr;
+    la.hfin = l + 1 < kSpkLayers ? nullptr : reinterpret_cast<float*>(ws + W.hfin);
+    rc = be.lstm(la, S.KS, dtype);
+    if (rc != QVC_OK) return rc;
+  }
+  SpkEmbedArgs ea{reinterpret_cast<const float*>(ws + W.hfin), reinterpret_cast<const float*>(blob + S.lin_w_off),
+                  reinterpret_cast<const float*>(blob + S.lin_b_off), g, U, n_part, H};
+  return be.spk_embed(ea);
+}
+
 }  // namespace qvc

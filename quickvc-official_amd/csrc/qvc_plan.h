@@ -342,4 +342,80 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
   return W;
 }
 
+// ---------------------------------------------------------------- speaker encoder (models.py:507-546)
+constexpr int kSpkLayers = 3;      // nn.LSTM(mel, hidden, 3), models.py:508-510
+constexpr int kSpkPartial = 128;   // embed_utterance(partial_frames=128, partial_hop=64), models.py:528
+constexpr int kSpkHop = 64;
+constexpr int kSpkCols = 16;       // partials per workgroup of the recurrence kernel (one MFMA column fragment)
+
+// Partials of one utterance: range(0, F-128, 64) plus the last 128 frames; the whole mel when F <= 128.
+inline int spk_partials(int mel_frames) {
+  return mel_frames > kSpkPartial ? ceil_div(mel_frames - kSpkPartial, kSpkHop) + 1 : 1;
+}
+inline int spk_steps(int mel_frames) { return mel_frames > kSpkPartial ? kSpkPartial : mel_frames; }
+inline int spk_start(int mel_frames, int i) {   // first mel frame of partial i
+  return i + 1 < spk_partials(mel_frames) ? i * kSpkHop : (mel_frames > kSpkPartial ? mel_frames - kSpkPartial : 0);
+}
+
+// The LSTM as GEMMs: per layer one batched input projection  xp = W_ih x + b_ih + b_hh  over all frames (the
+// conv kernel, M = 4H rows in PyTorch's gate order i,f,g,o) and one persistent launch that walks the steps with
+// W_hh streamed as MFMA A fragments.  Wave w of that launch owns hidden units [32w, 32w+32) of all four gates:
+// fragment f = 2*gate + half holds rows gate*H + 32w + 16*half + (0..15), so the gate math is lane-local.
+struct SpkPlan {
+  int32_t status = QVC_OK;
+  int32_t n_mel = 80, H = 0, HP = 0, NW = 0, KS = 0;
+  ConvDesc ih[kSpkLayers];
+  int64_t hh_off[kSpkLayers] = {};
+  int64_t hh_bytes = 0;
+  int64_t lin_w_off = 0, lin_b_off = 0;   // fp32 [H][H], [H]  (model_embedding_size = hidden, models.py:585)
+  int64_t blob_bytes = 0;
+};
+
+inline int spk_hh_row(const SpkPlan& S, int wave, int frag, int i) {   // packed position -> W_hh row or -1
+  const int unit = wave * 32 + (frag & 1) * 16 + i;
+  return unit < S.H ? (frag >> 1) * S.H + unit : -1;
+}
+
+inline SpkPlan build_spk_plan(const qvc_config& c) {
+  SpkPlan S;
+  S.n_mel = c.n_mel_channels > 0 ? c.n_mel_channels : 80;
+  S.H = c.gin_channels;
+  if (S.H <= 0 || S.H % 8 || S.H > 256 || S.n_mel > 1024 ||
+      (c.operand_dtype != QVC_BF16 && c.operand_dtype != QVC_F16)) { S.status = QVC_ERR_BAD_CONFIG; return S; }
+  S.HP = (int)align_up(S.H, 32); S.NW = S.HP / 32; S.KS = S.HP / kKStep;
+  int64_t off = 0;
+  for (int l = 0; l < kSpkLayers; ++l) {
+    S.ih[l] = make_conv(4 * S.H, l == 0 ? S.n_mel : S.H, 1, 1);
+    S.ih[l].w_off = off; off = align_up(off + S.ih[l].w_bytes(), 256);
+    S.ih[l].b_off = off; off = align_up(off + S.ih[l].b_bytes(), 256);
+  }
+  S.hh_bytes = (int64_t)S.NW * S.KS * 8 * kFragElems * 2;
+  for (int l = 0; l < kSpkLayers; ++l) { S.hh_off[l] = off; off = align_up(off + S.hh_bytes, 256); }
+  S.lin_w_off = off; off = align_up(off + (int64_t)S.H * S.H * 4, 256);
+  S.lin_b_off = off; off = align_up(off + (int64_t)S.H * 4, 256);
+  S.blob_bytes = off;
+  return S;
+}
+
+struct SpkWorkspace {
+  int64_t xp0 = 0;    // fp32 [U][F][4H]        layer-0 input projection, shared by overlapping partials
+  int64_t xp = 0;     // fp32 [P][S][4H]        layer-1/2 input projections
+  int64_t hseq = 0;   // op   [P][S][H]         hidden sequence of the previous layer
+  int64_t hfin = 0;   // fp32 [P][H]            final hidden state of the last layer
+  int64_t bytes = 0;
+};
+
+inline SpkWorkspace carve_spk_workspace(const SpkPlan& S, int U, int F) {
+  SpkWorkspace W;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off = align_up(off + n, 256); return o; };
+  const int64_t P = (int64_t)U * spk_partials(F), St = spk_steps(F);
+  W.xp0 = take((int64_t)U * F * 4 * S.H * 4);
+  W.xp = take(P * St * 4 * S.H * 4);
+  W.hseq = take(P * St * S.H * 2);
+  W.hfin = take(P * S.H * 4);
+  W.bytes = off;
+  return W;
+}
+
 }  // namespace qvc

@@ -43,6 +43,10 @@ class QvcEngine:
                 L.check(self.lib, self.lib.qvc_aux_create(ctypes.byref(self._aux)), "qvc_aux_create")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key = None
+        # speaker encoder: own blob, packed on first use from the same state dict
+        self._spk_sd = {k: v for k, v in state_dict.items() if k.startswith("enc_spk.")}
+        self._spk_blob: Optional[torch.Tensor] = None
+        self._spk_ws: Optional[torch.Tensor] = None
         n = model_config["gen_istft_hop_size"] * model_config["subbands"]
         for u in model_config["upsample_rates"]:
             n *= u
@@ -93,6 +97,30 @@ class QvcEngine:
                                          self._aux)
         L.check(self.lib, st, "qvc_infer_batch")
         return out
+
+    def speaker_embed(self, mel: torch.Tensor) -> torch.Tensor:
+        """SpeakerEncoder.embed_utterance for a batch (models.py:528-546): mel (U, n_mel, F) -> g (U, gin)."""
+        if mel.dim() != 3 or mel.shape[1] != int(self.cfg.n_mel_channels) or mel.shape[2] < 1:
+            raise ValueError(f"mel must be (U, {int(self.cfg.n_mel_channels)}, frames), got {tuple(mel.shape)}")
+        if self._spk_blob is None:
+            if not self._spk_sd:
+                raise L.QvcError("the state dict holds no enc_spk.* weights")
+            host = L.pack_weights(self.lib, self.cfg, self._spk_sd, which="spk")
+            self._spk_blob = _aligned_empty(host.numel(), self.device)
+            self._spk_blob.copy_(host)
+        mel = self._f32(mel, self.device)
+        U, _, F = mel.shape
+        n = int(self.lib.qvc_spk_workspace_bytes(ctypes.byref(self.cfg), U, F))
+        if n < 0:
+            L.check(self.lib, n, "qvc_spk_workspace_bytes")
+        if self._spk_ws is None or self._spk_ws.numel() < n:
+            self._spk_ws = _aligned_empty(n, self.device)
+        g = torch.empty(U, self.model_config["gin_channels"], dtype=torch.float32, device=self.device)
+        st = self.lib.qvc_speaker_embed(ctypes.byref(self.cfg), self._spk_blob.data_ptr(), mel.data_ptr(), g.data_ptr(),
+                                        U, F, self._spk_ws.data_ptr(), self._spk_ws.numel(),
+                                        torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_speaker_embed")
+        return g
 
     def infer_batch_timed(self, unit, g, noise, out=None, max_records: int = 512):
         """Same launches with per-launch HIP-event timing; returns (out, [dict(name, ms, flops, bytes)])."""

@@ -31,7 +31,7 @@ class QvcConfig(ctypes.Structure):
         ("resblock_kernel_sizes", ctypes.c_int32 * QVC_MAX_RESBLOCKS),
         ("resblock_dilations", (ctypes.c_int32 * 3) * QVC_MAX_RESBLOCKS),
         ("n_fft", ctypes.c_int32), ("hop", ctypes.c_int32), ("subbands", ctypes.c_int32), ("decoder", ctypes.c_int32),
-        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("n_mel_channels", ctypes.c_int32),
     ]
 
 
@@ -88,6 +88,14 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_conv1d_workspace_bytes.argtypes = [I, I, I, I]
         lib.qvc_conv1d.restype = ctypes.c_int
         lib.qvc_conv1d.argtypes = [V, V, V, V, I, I, I, I, I, I, ctypes.c_float, I, V, V, L, V, L, V]
+        lib.qvc_spk_blob_bytes.restype = L
+        lib.qvc_spk_blob_bytes.argtypes = [cfgp]
+        lib.qvc_spk_pack_weights.restype = ctypes.c_int
+        lib.qvc_spk_pack_weights.argtypes = [cfgp, P(QvcTensor), I, V, L]
+        lib.qvc_spk_workspace_bytes.restype = L
+        lib.qvc_spk_workspace_bytes.argtypes = [cfgp, I, I]
+        lib.qvc_speaker_embed.restype = ctypes.c_int
+        lib.qvc_speaker_embed.argtypes = [cfgp, V, V, V, I, I, V, L, V]
 
 
 _lib = None
@@ -102,7 +110,7 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 1:
+        if lib.qvc_abi_version() != 2:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -144,15 +152,20 @@ def make_config(mc: dict) -> QvcConfig:
     if dt not in DTYPES:
         raise QvcError(f"operand_dtype must be one of {sorted(DTYPES)}")
     c.operand_dtype = DTYPES[dt]
-    c.reserved0 = 0
+    c.n_mel_channels = int(mc.get("n_mel_channels", 80))
     return c
 
 
-def pack_weights(lib, cfg: QvcConfig, state_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """state_dict (reference keys) -> packed host blob (uint8 tensor, 256-byte aligned storage)."""
-    n = int(lib.qvc_blob_bytes(ctypes.byref(cfg)))
+def pack_weights(lib, cfg: QvcConfig, state_dict: Dict[str, torch.Tensor], which: str = "path") -> torch.Tensor:
+    """state_dict (reference keys) -> packed host blob (uint8 tensor, 256-byte aligned storage).
+
+    ``which``: "path" = enc_p / flow / dec (qvc_pack_weights), "spk" = the speaker encoder (qvc_spk_pack_weights).
+    """
+    bytes_fn, pack_fn = {"path": (lib.qvc_blob_bytes, lib.qvc_pack_weights),
+                         "spk": (lib.qvc_spk_blob_bytes, lib.qvc_spk_pack_weights)}[which]
+    n = int(bytes_fn(ctypes.byref(cfg)))
     if n < 0:
-        check(lib, n, "qvc_blob_bytes")
+        check(lib, n, bytes_fn.__name__)
     keep = []   # keep fp32 contiguous CPU copies alive during the call
     arr = (QvcTensor * len(state_dict))()
     i = 0
@@ -170,5 +183,5 @@ def pack_weights(lib, cfg: QvcConfig, state_dict: Dict[str, torch.Tensor]) -> to
     raw = torch.empty(n + 256, dtype=torch.uint8)
     shift = (-raw.data_ptr()) % 256
     blob = raw[shift:shift + n]
-    check(lib, lib.qvc_pack_weights(ctypes.byref(cfg), arr, i, blob.data_ptr(), n), "qvc_pack_weights")
+    check(lib, pack_fn(ctypes.byref(cfg), arr, i, blob.data_ptr(), n), pack_fn.__name__)
     return blob

@@ -180,7 +180,9 @@ class GeneratorParams(nn.Module):
 
 # ----------------------------------------------------------------------------- speaker encoder
 class SpeakerEncoder(nn.Module):
-    """models.py:507-546 -- stays PyTorch-ROCm host code (not on the HIP path).
+    """models.py:507-546 as a torch module: holds the enc_spk.* parameters under the reference's names and is
+    the fp32 torch reference of the HIP speaker-encoder kernels (``SynthesizerTrn.speaker_embed`` is what
+    ``infer`` calls).
 
     ``embed_utterance`` keeps the reference semantics: 128-frame partials at hop 64
     plus the last 128 frames, mean of the L2-normalised partial embeddings, *no*
@@ -293,8 +295,21 @@ class SynthesizerTrn(nn.Module):
         ``noise`` (1, inter, F) optionally replaces the internal N(0,1) draw of
         models.py:94 so a caller can reproduce a run.
         """
-        g = self.enc_spk.embed_utterance(mel.transpose(1, 2))                    # models.py:635
+        g = self.speaker_embed(mel)                                               # models.py:635
         return self.infer_batch(unit, g, noise)
+
+    @torch.no_grad()
+    def speaker_embed(self, mel: Tensor) -> Tensor:
+        """SpeakerEncoder.embed_utterance (models.py:528-546) for a batch: mel (U, 80, F') -> g (U, gin).
+
+        Runs the persistent-LSTM HIP kernels (csrc/qvc_spk.hip).  Speaker widths the kernel does not cover
+        (gin > 256 or gin % 8 != 0) go through ``enc_spk`` -- torch.nn.LSTM on the same GPU -- one utterance
+        at a time, as the reference does.
+        """
+        gin = self.model_config["gin_channels"]
+        if gin <= 256 and gin % 8 == 0:
+            return self.engine().speaker_embed(mel)
+        return torch.cat([self.enc_spk.embed_utterance(m[None].transpose(1, 2)) for m in mel], 0)
 
     @torch.no_grad()
     def infer_batch(self, unit: Tensor, g: Tensor, noise: Optional[Tensor] = None) -> Tensor:

@@ -18,6 +18,8 @@ def load_emu():
     P, I, Lg, V = ctypes.POINTER, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
     lib.qvc_emu_infer_batch.restype = ctypes.c_int
     lib.qvc_emu_infer_batch.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, Lg]
+    lib.qvc_emu_speaker_embed.restype = ctypes.c_int
+    lib.qvc_emu_speaker_embed.argtypes = [P(L.QvcConfig), V, V, V, I, I, V, Lg]
     lib.qvc_emu_tap_offset.restype = Lg
     lib.qvc_emu_tap_offset.argtypes = [P(L.QvcConfig), I, I, I]
     return lib
@@ -64,3 +66,24 @@ def emu_infer(model_config, sd, unit, g, noise, dtype="f16", taps=None):
         off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 2)
         taps["rb0"] = ws[off:off + B * t1 * ch0 * 2].view(td).reshape(B, t1, ch0).float()
     return out
+
+
+def emu_speaker_embed(model_config, sd, mel, dtype="f16"):
+    """Host replay of qvc_speaker_embed: mel (U, n_mel, F) -> g (U, gin)."""
+    from quickvc_official_amd import lib as L
+    hip = L.load_library()
+    emu = load_emu()
+    cfg = L.make_config(dict(model_config, operand_dtype=dtype))
+    blob = L.pack_weights(hip, cfg, {k: v for k, v in sd.items() if k.startswith("enc_spk.")}, which="spk")
+    U, _, F = mel.shape
+    n_ws = int(hip.qvc_spk_workspace_bytes(ctypes.byref(cfg), U, F))
+    assert n_ws > 0
+    ws = torch.zeros(n_ws + 256, dtype=torch.uint8)
+    shift = (-ws.data_ptr()) % 256
+    ws = ws[shift:shift + n_ws]
+    mel = mel.float().contiguous()
+    g = torch.empty(U, int(cfg.gin_channels))
+    st = emu.qvc_emu_speaker_embed(ctypes.byref(cfg), blob.data_ptr(), mel.data_ptr(), g.data_ptr(), U, F,
+                                   ws.data_ptr(), n_ws)
+    assert st == 0, hip.qvc_status_string(st)
+    return g

@@ -292,3 +292,72 @@ def test_wide_config_takes_the_fallback_paths(lib, dev):
     assert sum(n.startswith("conv<") for n in names) == 2 + 8 + 1 + 2 + 1 + 18   # + 9 x (conv1, conv2) of stage 1
     for b in range(2):
         assert snr_db(ref[b], out[b].cpu()) >= 45.0
+
+
+# ------------------------------------------------------------------ speaker encoder
+def _g_err(ref, got):
+    ref, got = np.asarray(ref, np.float64), np.asarray(got, np.float64)
+    return float(np.sqrt(((ref - got) ** 2).sum(-1) / (ref ** 2).sum(-1)).max())
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("bf16", 1e-2)])
+def test_speaker_embed_matches_oracle(lib, dev, dtype, tol):
+    """qvc_speaker_embed (persistent-LSTM kernels) vs SpeakerEncoder.embed_utterance restated in the oracle
+    (models.py:507-546; the oracle itself is pinned by golden/mini_spk.npz): full-width encoder (gin 256),
+    mel lengths on both sides of the 128-frame branch and of the 64-frame hop, batches of utterances.
+    Tolerance: relative L2 error of the embedding, operands rounded to the MFMA type every step."""
+    from quickvc_official_amd.synth import make_synthetic_mel
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    sdf = {k: v.float() for k, v in sd.items()}
+    eng = _engine(entry, sd, dev, dtype)
+    for frames, U in ((1, 1), (100, 2), (128, 1), (129, 3), (250, 32), (300, 2), (321, 1)):
+        mel = torch.cat([make_synthetic_mel(frames, 80, seed=11 * frames + u) for u in range(U)], 0)
+        g = eng.speaker_embed(mel.to(dev))
+        torch.cuda.synchronize()
+        assert g.shape == (U, 256) and g.dtype == torch.float32
+        ref = torch.cat([oracle.speaker_embed_utterance(sdf, mel[u:u + 1].transpose(1, 2)) for u in range(U)], 0)
+        assert _g_err(ref.numpy(), g.cpu().numpy()) <= tol, (frames, U)
+
+
+def test_speaker_embed_golden_and_narrow_widths(lib, dev):
+    """Reference-generated embeddings (golden/mini_spk.npz, gin 64: two waves per workgroup) and a width that
+    is not a multiple of 32 (gin 24: padded hidden units must stay zero)."""
+    import os
+    import helpers
+    from quickvc_official_amd.synth import make_synthetic_mel
+    entry, _ = load_case("mini")
+    spk = dict(np.load(os.path.join(helpers.GOLDEN, "mini_spk.npz")))
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    for frames in (100, 128, 300):
+        mel = make_synthetic_mel(frames, 80, seed=7 + frames)
+        g = eng.speaker_embed(mel.to(dev))
+        assert _g_err(spk[f"g_{frames}"], g.cpu().numpy()) <= 1e-3, frames
+    entry, _ = load_case("odd")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    sdf = {k: v.float() for k, v in sd.items()}
+    eng = _engine(entry, sd, dev, "f16")
+    mel = torch.cat([make_synthetic_mel(200, 80, seed=90 + u) for u in range(5)], 0)
+    g = eng.speaker_embed(mel.to(dev))
+    ref = torch.cat([oracle.speaker_embed_utterance(sdf, mel[u:u + 1].transpose(1, 2)) for u in range(5)], 0)
+    assert _g_err(ref.numpy(), g.cpu().numpy()) <= 4e-3
+
+
+def test_speaker_embed_bad_args(lib, dev):
+    import ctypes
+    from quickvc_official_amd import lib as L
+    entry, _ = load_case("mini")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    with pytest.raises(ValueError):
+        eng.speaker_embed(torch.zeros(1, 79, 50, device=dev))
+    mel = torch.zeros(1, 80, 50, device=dev)
+    eng.speaker_embed(mel)
+    g = torch.empty(1, 64, device=dev)
+    st = eng.lib.qvc_speaker_embed(ctypes.byref(eng.cfg), eng._spk_blob.data_ptr(), mel.data_ptr(), g.data_ptr(), 1, 50,
+                                   eng._spk_ws.data_ptr(), 16, None)
+    assert st == -5      # QVC_ERR_SMALL_BUFFER
+    st = eng.lib.qvc_speaker_embed(ctypes.byref(eng.cfg), eng._spk_blob.data_ptr(), None, g.data_ptr(), 1, 50,
+                                   eng._spk_ws.data_ptr(), eng._spk_ws.numel(), None)
+    assert st == -1      # QVC_ERR_BAD_ARG

@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "qvc.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
-    assert len(names) >= 14
+    assert len(names) >= 18
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 1
+    assert built.qvc_abi_version() == 2
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
 
 
@@ -72,6 +72,45 @@ def test_pack_weights_error_codes(built):
     cfg3 = L.make_config(dict(model.model_config)); cfg3.inter_channels = 50
     assert built.qvc_workspace_bytes(ctypes.byref(cfg3), 1, 10) == -2
     assert built.qvc_workspace_bytes(ctypes.byref(cfg), 0, 10) == -1
+
+
+def test_speaker_encoder_pack_and_host_emulation(built):
+    """Speaker-encoder blob (qvc_spk_pack_weights) + its launch sequence replayed on the CPU vs the oracle's
+    SpeakerEncoder.embed_utterance (models.py:507-546), incl. the reference-generated golden embeddings."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd import lib as L
+    from quickvc_official_amd.synth import make_synthetic_mel
+    from emu import emu_speaker_embed
+    import helpers
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import qvc_oracle as oracle
+    entry, _ = load_case("mini")
+    model, sd, _u, _g, _n = regenerate(entry)
+    spk = dict(np.load(os.path.join(helpers.GOLDEN, "mini_spk.npz")))
+    err = lambda ref, got: float(np.sqrt(((np.asarray(ref, np.float64) - np.asarray(got, np.float64)) ** 2).sum(-1)
+                                         / (np.asarray(ref, np.float64) ** 2).sum(-1)).max())
+    for frames in (100, 128, 300):
+        mel = make_synthetic_mel(frames, 80, seed=7 + frames)
+        assert err(spk[f"g_{frames}"], emu_speaker_embed(model.model_config, sd, mel).numpy()) <= 4e-3
+    # batch of utterances, a width that is not a multiple of 32 (padded hidden units), bf16 operands
+    entry, _ = load_case("odd")
+    model, sd, _u, _g, _n = regenerate(entry)
+    sdf = {k: v.float() for k, v in sd.items()}
+    mel = torch.cat([make_synthetic_mel(140, 80, seed=40 + u) for u in range(3)], 0)
+    ref = torch.cat([oracle.speaker_embed_utterance(sdf, mel[u:u + 1].transpose(1, 2)) for u in range(3)], 0).numpy()
+    assert err(ref, emu_speaker_embed(model.model_config, sd, mel).numpy()) <= 4e-3
+    assert err(ref, emu_speaker_embed(model.model_config, sd, mel, dtype="bf16").numpy()) <= 3e-2
+    # error codes
+    cfg = L.make_config(model.model_config)
+    spk_sd = {k: v for k, v in sd.items() if k.startswith("enc_spk.")}
+    with pytest.raises(L.QvcError, match="missing"):
+        L.pack_weights(built, cfg, {k: v for k, v in spk_sd.items() if k != "enc_spk.lstm.bias_hh_l1"}, which="spk")
+    bad = dict(spk_sd); bad["enc_spk.lstm.weight_ih_l0"] = spk_sd["enc_spk.lstm.weight_ih_l0"][:, :-1]
+    with pytest.raises(L.QvcError, match="shape"):
+        L.pack_weights(built, cfg, bad, which="spk")
+    cfg2 = L.make_config(dict(model.model_config)); cfg2.gin_channels = 320
+    assert built.qvc_spk_blob_bytes(ctypes.byref(cfg2)) == -2
+    assert built.qvc_spk_workspace_bytes(ctypes.byref(cfg), 0, 10) == -1
 
 
 def test_weight_norm_and_flip_folding_change_nothing(built):
