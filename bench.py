@@ -169,6 +169,25 @@ def main() -> None:
                               "launches": v["launches"] // reps} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
         }
 
+        # ---- the step in front of the path: speaker embeddings of the batch's targets in one call.
+        #      Reported beside the metric, never part of `value` (the hot path starts after the speaker encoder).
+        try:
+            from quickvc_official_amd.synth import make_synthetic_mel
+            mel = torch.cat([make_synthetic_mel(FRAMES, 80, seed=9000 + i) for i in range(B)], 0).to(device)
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    engine.speaker_embed(mel)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(10):
+                    engine.speaker_embed(mel)
+                e1.record(stream)
+            stream.synchronize()
+            result["speaker_encoder"] = {"ms_per_call": e0.elapsed_time(e1) / 10, "utterances": B, "mel_frames": FRAMES,
+                                         "kernel": "3 x (input-projection conv + persistent LSTM launch) + embed"}
+        except Exception as exc:                                  # diagnostics only: never fail the bench line
+            result["speaker_encoder"] = {"error": str(exc)[:200]}
+
         # ---- parity + CPU baseline on a bounded sample of the same workload (oracle = checker / baseline only)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

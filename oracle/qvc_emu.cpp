@@ -392,7 +392,7 @@ struct EmuBackend {
           c[j] = sig(gate[H + j]) * c[j] + sig(gate[j]) * std::tanh(gate[2 * H + j]);
           hn[j] = sig(gate[3 * H + j]) * std::tanh(c[j]);
           h[j] = round_op(hn[j], dtype);
-          if (a.hseq) static_cast<uint16_t*>(a.hseq)[((size_t)p * a.S + t) * H + j] = dtype == QVC_F16 ? to_f16(h[j]) : to_bf16(h[j]);
+          if (a.hseq) static_cast<uint16_t*>(a.hseq)[((size_t)p * a.S + t) * HP + j] = dtype == QVC_F16 ? to_f16(h[j]) : to_bf16(h[j]);
         }
       }
       if (a.hfin) std::memcpy(a.hfin + (size_t)p * H, hn.data(), (size_t)H * 4);

@@ -116,7 +116,7 @@ struct LstmArgs {
   int32_t shared;       // 1: xp is [U][F][4H], partial p reads frames spk_start(p)+t; 0: xp is [P][S][4H]
   int32_t F, n_part, S, P, H;
   const void* w_hh;     // [wave][k-step][8 fragments][64 lanes][8], see spk_hh_row
-  void* hseq;           // [P][S][H] operand type: input of the next layer (null on the last layer)
+  void* hseq;           // [P16][S][HP] operand type (P, H padded to 16 / 32): input of the next layer (null on the last)
   float* hfin;          // [P][H] fp32: h after the last step (last layer only)
 };
 

@@ -292,7 +292,7 @@ int spk_path(const SpkPlan& S, int dtype, const char* blob, char* ws, const SpkW
       ca.y32 = reinterpret_cast<float*>(ws + W.xp0); ca.y32_bs = (int64_t)F * 4 * H; ca.y32_ts = 4 * H;
       batch = U;
     } else {
-      ca.x = ws + W.hseq; ca.x_kind = XK_OP_FM; ca.x_bs = (int64_t)St * H; ca.x_ts = H; ca.T_in = St;
+      ca.x = ws + W.hseq; ca.x_kind = XK_OP_FM; ca.x_bs = (int64_t)St * S.HP; ca.x_ts = S.HP; ca.T_in = St;
       ca.Nq = St; ca.T_out = St;
       ca.y32 = reinterpret_cast<float*>(ws + W.xp); ca.y32_bs = (int64_t)St * 4 * H; ca.y32_ts = 4 * H;
       batch = P;

@@ -400,7 +400,7 @@ inline SpkPlan build_spk_plan(const qvc_config& c) {
 struct SpkWorkspace {
   int64_t xp0 = 0;    // fp32 [U][F][4H]        layer-0 input projection, shared by overlapping partials
   int64_t xp = 0;     // fp32 [P][S][4H]        layer-1/2 input projections
-  int64_t hseq = 0;   // op   [P][S][H]         hidden sequence of the previous layer
+  int64_t hseq = 0;   // op   [P16][S][HP]      hidden sequence of the previous layer (P, H padded: unconditional stores)
   int64_t hfin = 0;   // fp32 [P][H]            final hidden state of the last layer
   int64_t bytes = 0;
 };
@@ -412,7 +412,7 @@ inline SpkWorkspace carve_spk_workspace(const SpkPlan& S, int U, int F) {
   const int64_t P = (int64_t)U * spk_partials(F), St = spk_steps(F);
   W.xp0 = take((int64_t)U * F * 4 * S.H * 4);
   W.xp = take(P * St * 4 * S.H * 4);
-  W.hseq = take(P * St * S.H * 2);
+  W.hseq = take(align_up(P, kSpkCols) * St * S.HP * 2);
   W.hfin = take(P * S.H * 4);
   W.bytes = off;
   return W;

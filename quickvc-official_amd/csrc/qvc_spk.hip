@@ -21,22 +21,24 @@
 
 namespace qvc {
 
-template <typename T, int KS, int KREG, int PF>
+template <typename T, int KS, int KREG, int KLDS, int RING, bool LAST>
 __global__ __launch_bounds__(512) void lstm_layer_kernel(const LstmArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
-  constexpr int KSS = KS - KREG;            // k-steps streamed per time step
-  constexpr int RING = PF + 1;
-  static_assert(KSS >= 1 && KSS % RING == 0, "ring slots must repeat every time step");
-  constexpr int HPs = KS * 32 + 8;          // LDS row of one partial's h (+16 B: rows start in different banks)
+  constexpr int KRES = KREG + KLDS;         // resident k-steps: [0, KREG) in registers, [KREG, KRES) in LDS
+  constexpr int KSS = KS - KRES;            // k-steps streamed per time step
+  static_assert(KSS >= 1 && RING >= 1 && KSS % RING == 0, "ring slots must repeat every time step");
+  constexpr int HP = KS * 32;
+  constexpr int HPs = HP + 8;               // LDS row of one partial's h (+16 B: rows start in different banks)
+  constexpr int NL = KLDS * 8;              // LDS-resident fragments per wave
+  constexpr int LW = NL < 4 ? NL : 4;       // ... read through a rolling window of LW registers
   extern __shared__ __align__(16) char smem[];
   T* hb = reinterpret_cast<T*>(smem);       // [2][16][HPs]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int col = lane & 15, quad = lane >> 4;
   const int p = blockIdx.x * kSpkCols + col;
-  const bool valid = p < a.P;
-  const int pc = valid ? p : a.P - 1;
+  const int pc = p < a.P ? p : a.P - 1;     // columns past the last partial replay it (their stores land in padding)
   const int H = a.H, H4 = 4 * H;
 
   const float* xb;
@@ -47,13 +49,14 @@ __global__ __launch_bounds__(512) void lstm_layer_kernel(const LstmArgs a) {
   } else {
     xb = a.xp + (size_t)pc * a.S * H4;
   }
-  // fragment f = 2*gate + half: rows gate*H + 32w + 16*half + 4*quad + (0..3)
+  // fragment f = 2*gate + half: rows gate*H + 32w + 16*half + 4*quad + (0..3).  Units >= H (H not a multiple of
+  // 32) have zero weights; their h is forced to 0 and their loads are pointed at row 0 -- no branches in the step
+  // loop, so hipcc can count the outstanding loads instead of draining them (s_waitcnt vmcnt(0)) at every use.
   const int unit0 = w * 32 + quad * 4;
-  bool live[2];
+  const bool live[2] = {unit0 < H, unit0 + 16 < H};
   int ro[8];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) ro[f] = (f >> 1) * H + unit0 + (f & 1) * 16;
-  live[0] = unit0 < H; live[1] = unit0 + 16 < H;
+  for (int f = 0; f < 8; ++f) ro[f] = live[f & 1] ? (f >> 1) * H + unit0 + (f & 1) * 16 : 0;
 
   const frag* wp = static_cast<const frag*>(a.w_hh) + (size_t)w * KS * 8 * 64 + lane;
   frag areg[KREG > 0 ? KREG : 1][8];
@@ -61,81 +64,112 @@ __global__ __launch_bounds__(512) void lstm_layer_kernel(const LstmArgs a) {
   for (int k = 0; k < KREG; ++k)
 #pragma unroll
     for (int f = 0; f < 8; ++f) areg[k][f] = wp[(k * 8 + f) * 64];
+  // LDS-resident k-steps: each wave keeps its own fragments, one 16-byte slot per lane (conflict-free b128 access)
+  frag* wl = reinterpret_cast<frag*>(smem + (size_t)2 * kSpkCols * HPs * sizeof(T)) + (size_t)w * NL * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) wl[i * 64] = wp[(KREG * 8 + i) * 64];
+  // streamed k-steps: slot s % RING is refilled with k-step s + RING right after the MFMAs that read it, so RING
+  // k-steps (8 KiB per wave each) stay in flight through the gate phase and the barrier
   frag ring[RING][8];
 #pragma unroll
-  for (int u = 0; u < PF; ++u)
+  for (int u = 0; u < RING; ++u)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) ring[u][f] = wp[((KREG + u % KSS) * 8 + f) * 64];
+    for (int f = 0; f < 8; ++f) ring[u][f] = wp[((KRES + u) * 8 + f) * 64];
 
-  for (int i = tid; i < 2 * kSpkCols * HPs / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(hb)[i] = 0u;   // h0 = 0
-  float c[2][4];
+  for (int i = tid; i < kSpkCols * HPs; i += blockDim.x) reinterpret_cast<uint32_t*>(hb)[i] = 0u;   // h0 = 0 (both buffers)
+  float c[2][4], hf[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[h][j] = 0.f;
+    for (int j = 0; j < 4; ++j) { c[h][j] = 0.f; hf[h][j] = 0.f; }
 
   f32x4 xv[8];
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
-    xv[f] = live[f & 1] ? *reinterpret_cast<const f32x4*>(xb + ro[f]) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < 8; ++f) xv[f] = *reinterpret_cast<const f32x4*>(xb + ro[f]);
+  T* hs = LAST ? nullptr : static_cast<T*>(a.hseq) + (size_t)p * a.S * HP + unit0;   // [P16][S][HP]
   __syncthreads();
 
   for (int t = 0; t < a.S; ++t) {
     // the stream addresses repeat every step; keep hipcc from hoisting those loads out of the loop (it would
     // try to hold all of W_hh in registers and spill)
-    const frag* wt = wp;
-    asm volatile("" : "+v"(wt));
+    // (an opaque OFFSET, not an opaque pointer: the latter loses the address space and turns the stream into
+    // flat loads, which also count on lgkmcnt and serialise with the LDS reads)
+    int wofs = 0;
+    asm volatile("" : "+v"(wofs));
+    const frag* wt = wp + wofs;
     const T* hcur = hb + (size_t)(t & 1) * kSpkCols * HPs + col * HPs + quad * 8;
     T* hnxt = hb + (size_t)((t + 1) & 1) * kSpkCols * HPs + col * HPs;
     f32x4 acc[8];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) acc[f] = xv[f];
-    if (t + 1 < a.S) {
-      const float* xn = xb + (size_t)(t + 1) * H4;
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-        if (live[f & 1]) xv[f] = *reinterpret_cast<const f32x4*>(xn + ro[f]);
-    }
+    for (int f = 0; f < 8; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // order: streamed k-steps first (prefetched during the previous gate phase), then LDS-, then register-resident
+    auto kmap = [](int kk) { return kk < KSS ? KRES + kk : (kk - KSS < KLDS ? KREG + (kk - KSS) : kk - KSS - KLDS); };
     frag bq[2];
-    bq[0] = *reinterpret_cast<const frag*>(hcur);
+    bq[0] = *reinterpret_cast<const frag*>(hcur + kmap(0) * 32);
+    frag lw[LW > 0 ? LW : 1];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) bq[(ks + 1) & 1] = *reinterpret_cast<const frag*>(hcur + (ks + 1) * 32);
-      if (ks < KREG) {
+    for (int i = 0; i < LW; ++i) lw[i] = wl[i * 64];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) acc[f] = O::mfma(areg[ks][f], bq[ks & 1], acc[f]);
-      } else {
-        const int s = ks - KREG;
-        {   // prefetch PF streamed k-steps ahead; wraps into the next time step (same addresses)
-          const int sn = (s + PF) % KSS;
+    for (int kk = 0; kk < KS; ++kk) {
+      const int ks = kmap(kk);
+      if (kk + 1 < KS) bq[(kk + 1) & 1] = *reinterpret_cast<const frag*>(hcur + kmap(kk + 1) * 32);
+      if (kk < KSS) {
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance: hipcc would sink the loads to their use
 #pragma unroll
-          for (int f = 0; f < 8; ++f) ring[(s + PF) % RING][f] = wt[((KREG + sn) * 8 + f) * 64];
+        for (int f = 0; f < 8; ++f) acc[f] = O::mfma(ring[kk % RING][f], bq[kk & 1], acc[f]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) ring[kk % RING][f] = wt[((KRES + (kk + RING) % KSS) * 8 + f) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (ks >= KREG) {
+        if constexpr (NL > 0) {
+#pragma unroll
+          for (int f = 0; f < 8; ++f) {
+            const int i = (ks - KREG) * 8 + f;
+            acc[f] = O::mfma(lw[i % LW], bq[kk & 1], acc[f]);
+            if (i + LW < NL) lw[i % LW] = wl[(i + LW) * 64];
+          }
         }
+      } else {
 #pragma unroll
-        for (int f = 0; f < 8; ++f) acc[f] = O::mfma(ring[s % RING][f], bq[ks & 1], acc[f]);
+        for (int f = 0; f < 8; ++f) acc[f] = O::mfma(areg[ks][f], bq[kk & 1], acc[f]);
       }
+    }
+    // + input projection of this step, then fetch the next step's into the same registers.  Issued here, the
+    // fetch (cold: xp is streamed from HBM when many partials are in flight) has the whole gate phase to land;
+    // issued at the top of the step it would sit in front of the ring refills in the in-order return queue and
+    // stall the MFMAs behind an HBM round trip (measured: 4.8 vs 3.4 us per step at 96 partials).
+    {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc[f] += xv[f];
+      const float* xn = xb + (size_t)(t + 1 < a.S ? t + 1 : t) * H4;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) xv[f] = *reinterpret_cast<const f32x4*>(xn + ro[f]);
     }
     // gates (torch.nn.LSTM order i, f, g, o), cell and hidden state of this lane's 2 x 4 units
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       typename O::quad hq;
-      float hf[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float gi = fast_sigmoid(acc[0 + h][j]), gf = fast_sigmoid(acc[2 + h][j]);
         const float gg = fast_tanh(acc[4 + h][j]), go = fast_sigmoid(acc[6 + h][j]);
         c[h][j] = gf * c[h][j] + gi * gg;
-        hf[j] = live[h] ? go * fast_tanh(c[h][j]) : 0.f;
-        hq[j] = O::cvt(hf[j]);
+        hf[h][j] = live[h] ? go * fast_tanh(c[h][j]) : 0.f;
+        hq[j] = O::cvt(hf[h][j]);
       }
-      const int unit = unit0 + h * 16;
-      *reinterpret_cast<typename O::quad*>(hnxt + unit) = hq;
-      if (valid && live[h]) {
-        if (a.hseq) *reinterpret_cast<typename O::quad*>(static_cast<T*>(a.hseq) + ((size_t)p * a.S + t) * H + unit) = hq;
-        if (a.hfin && t == a.S - 1) *reinterpret_cast<float4*>(a.hfin + (size_t)p * H + unit) = make_float4(hf[0], hf[1], hf[2], hf[3]);
-      }
+      *reinterpret_cast<typename O::quad*>(hnxt + unit0 + h * 16) = hq;
+      if constexpr (!LAST) *reinterpret_cast<typename O::quad*>(hs + (size_t)t * HP + h * 16) = hq;
     }
     __syncthreads();
+  }
+  if constexpr (LAST) {
+    if (p < a.P) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (live[h]) *reinterpret_cast<float4*>(a.hfin + (size_t)p * H + unit0 + h * 16) = make_float4(hf[h][0], hf[h][1], hf[h][2], hf[h][3]);
+    }
   }
 }
 
@@ -182,30 +216,50 @@ __global__ __launch_bounds__(256) void spk_embed_kernel(const SpkEmbedArgs a) {
   }
 }
 
-template <typename T, int KS>
-static int launch_lstm_ks(const LstmArgs& a, int NW, hipStream_t stream) {
+template <typename T, int KS, int KREG, int KLDS, int RING, bool LAST>
+static int launch_lstm_last(const LstmArgs& a, hipStream_t stream) {
   constexpr int HPs = KS * 32 + 8;
-  const size_t lds = (size_t)2 * kSpkCols * HPs * sizeof(T);
-  const dim3 grid((unsigned)ceil_div(a.P, kSpkCols)), block((unsigned)NW * 64);
-  // resident k-steps / ring depth per width: registers = 32*(KREG + PF + 1) for the weights (+ ~100 others)
-  if constexpr (KS == 8) hipLaunchKernelGGL((lstm_layer_kernel<T, 8, 0, 3>), grid, block, lds, stream, a);
-  else if constexpr (KS % 4 == 0) hipLaunchKernelGGL((lstm_layer_kernel<T, KS, 0, 3>), grid, block, lds, stream, a);
-  else if constexpr (KS % 2 == 0) hipLaunchKernelGGL((lstm_layer_kernel<T, KS, 0, 1>), grid, block, lds, stream, a);
-  else hipLaunchKernelGGL((lstm_layer_kernel<T, KS, 0, 0>), grid, block, lds, stream, a);
+  const size_t lds = (size_t)2 * kSpkCols * HPs * sizeof(T) + (size_t)KS * KLDS * 8 * 1024;
+  auto kern = lstm_layer_kernel<T, KS, KREG, KLDS, RING, LAST>;
+  static bool attr_done = false;                             // one-time opt-in for > 64 KiB dynamic LDS
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return QVC_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.P, kSpkCols)), dim3((unsigned)KS * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+template <typename T, int KS, int KREG, int KLDS, int RING>
+static int launch_lstm_variant(const LstmArgs& a, hipStream_t stream) {
+  if ((a.hseq == nullptr) == (a.hfin == nullptr)) return QVC_ERR_BAD_ARG;
+  return a.hseq ? launch_lstm_last<T, KS, KREG, KLDS, RING, false>(a, stream) : launch_lstm_last<T, KS, KREG, KLDS, RING, true>(a, stream);
+}
+
+template <typename T, int KS>
+static int launch_lstm_ks(const LstmArgs& a, hipStream_t stream) {
+  // <KREG, KLDS, RING>: k-steps resident in registers / in LDS (64 KiB each at 8 waves), ring slots of the rest
+  // Measured on MI355X at H = 256 (3 layers x 128 steps, one workgroup): all streamed 1.99 ms; 2 k-steps in
+  // LDS 1.68 ms; 2 in LDS + 2 in registers 1.36 ms (more residency spills).  Step time = 1.9 us (gate math on the
+  // quarter-rate exp/rcp units, 64 MFMAs, barrier) + 0.4 us per streamed k-step (64 KiB through the 64 B/clk L1).
+  if constexpr (KS == 8) return launch_lstm_variant<T, 8, 2, 2, 2>(a, stream);
+  else if constexpr (KS % 4 == 0) return launch_lstm_variant<T, KS, 0, 0, 4>(a, stream);
+  else if constexpr (KS % 2 == 0) return launch_lstm_variant<T, KS, 0, 0, 2>(a, stream);
+  else return launch_lstm_variant<T, KS, 0, 0, 1>(a, stream);
 }
 
 template <typename T>
 static int launch_lstm(const LstmArgs& a, int KS, hipStream_t stream) {
   switch (KS) {
-    case 1: return launch_lstm_ks<T, 1>(a, KS, stream);
-    case 2: return launch_lstm_ks<T, 2>(a, KS, stream);
-    case 3: return launch_lstm_ks<T, 3>(a, KS, stream);
-    case 4: return launch_lstm_ks<T, 4>(a, KS, stream);
-    case 5: return launch_lstm_ks<T, 5>(a, KS, stream);
-    case 6: return launch_lstm_ks<T, 6>(a, KS, stream);
-    case 7: return launch_lstm_ks<T, 7>(a, KS, stream);
-    case 8: return launch_lstm_ks<T, 8>(a, KS, stream);
+    case 1: return launch_lstm_ks<T, 1>(a, stream);
+    case 2: return launch_lstm_ks<T, 2>(a, stream);
+    case 3: return launch_lstm_ks<T, 3>(a, stream);
+    case 4: return launch_lstm_ks<T, 4>(a, stream);
+    case 5: return launch_lstm_ks<T, 5>(a, stream);
+    case 6: return launch_lstm_ks<T, 6>(a, stream);
+    case 7: return launch_lstm_ks<T, 7>(a, stream);
+    case 8: return launch_lstm_ks<T, 8>(a, stream);
   }
   return QVC_ERR_BAD_CONFIG;
 }
