@@ -240,9 +240,10 @@ static int launch_lstm_variant(const LstmArgs& a, hipStream_t stream) {
 template <typename T, int KS>
 static int launch_lstm_ks(const LstmArgs& a, hipStream_t stream) {
   // <KREG, KLDS, RING>: k-steps resident in registers / in LDS (64 KiB each at 8 waves), ring slots of the rest
-  // Measured on MI355X at H = 256 (3 layers x 128 steps, one workgroup): all streamed 1.99 ms; 2 k-steps in
-  // LDS 1.68 ms; 2 in LDS + 2 in registers 1.36 ms (more residency spills).  Step time = 1.9 us (gate math on the
-  // quarter-rate exp/rcp units, 64 MFMAs, barrier) + 0.4 us per streamed k-step (64 KiB through the 64 B/clk L1).
+  // Measured on MI355X at H = 256 (3 layers x 128 steps, one workgroup): all streamed 1.99 ms; 2 k-steps in LDS
+  // 1.68 ms; 2 in LDS + 2 in registers 1.24 ms (more residency spills).  Per step (3.0 us): ~0.4 us per streamed
+  // k-step (64 KiB through the 64 B/clk L1), 0.3 us for the xp fetch (another 64 KiB), 0.25 us gate math, the
+  // rest 64 MFMAs per wave + LDS round trip + barrier (ablations: no gates 1.15 ms, no xp fetch 1.14 ms).
   if constexpr (KS == 8) return launch_lstm_variant<T, 8, 2, 2, 2>(a, stream);
   else if constexpr (KS % 4 == 0) return launch_lstm_variant<T, KS, 0, 0, 4>(a, stream);
   else if constexpr (KS % 2 == 0) return launch_lstm_variant<T, KS, 0, 0, 2>(a, stream);
