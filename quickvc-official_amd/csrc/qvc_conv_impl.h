@@ -538,19 +538,21 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
 
 
 // ------------------------------------------------------------------ fused WaveNet layer
-// FW = tanh (= sigmoid = res = skip) fragments per wave; the 4 waves split the channels, so one
-// workgroup owns ALL 2h gate rows of its NF*16 frames, gates them into an LDS tile and runs the 1x1
-// res/skip GEMM from there: one launch per layer, the gated activations never leave the CU.
-template <typename T, int FW, int NF, bool LAST>
-__global__ __launch_bounds__(256) void wn_layer_kernel(const WnArgs a) {
+// One wave per 16 channels (blockDim = HP/16 waves <= WV, see wn_layout in qvc_plan.h): wave w holds the tanh,
+// sigmoid, res and skip rows of channels [16w, 16w+16), so one workgroup owns ALL 2h gate rows of its NF*16
+// frames, gates them into an LDS tile and runs the 1x1 res/skip GEMM from there: one launch per layer, the
+// gated activations never leave the CU.
+template <typename T, int NF, bool LAST, int WV>
+__global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
   using quad = typename O::quad;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int FW = 1;
   constexpr int NT = NF * 16;
   constexpr int MF1 = 2 * FW, MF2 = LAST ? FW : 2 * FW;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, NTH = blockDim.x;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
@@ -566,12 +568,12 @@ __global__ __launch_bounds__(256) void wn_layer_kernel(const WnArgs a) {
   if (!QVC_ABL(0)) {   // ---- stage x (fp32 -> operand type), rows [q0-left, q0-left+R)
     const int total = R * cpr;
     constexpr int kU = 4;
-    for (int base = tid; base < total; base += 256 * kU) {
+    for (int base = tid; base < total; base += NTH * kU) {
       float4 v0[kU], v1[kU];
       int dst[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const int idx = base + u * 256;
+        const int idx = base + u * NTH;
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = q0 - left + r;
         const bool ok = idx < total && ti >= 0 && ti < a.T && (c8 * 8 < a.H);
@@ -685,19 +687,20 @@ __global__ __launch_bounds__(256) void wn_layer_kernel(const WnArgs a) {
 
 
 // ------------------------------------------------------------------ whole WaveNet stack, one launch
-// PM = A fragments per wave of the optional fused post conv (0: none)
-template <typename T, int FW, int NF, int PM>
-__global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
+// PM = A fragments per wave of the optional fused post conv (0: none).  One wave per 16 channels, as above.
+template <typename T, int NF, int PM, int WV>
+__global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
   using quad = typename O::quad;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int FW = 1;
   constexpr int NB = NF * 16;                 // frames carried by this workgroup (output tile + halo)
   constexpr int MF = 2 * FW;
   // the skip sum is only needed for the column fragments that overlap the 32 output frames
   constexpr int OLO = NF > 3 ? 1 : 0, ON = 3;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, NTH = blockDim.x;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
   char* acts = smem + R * rowbytes;
 
   // zero the x tile once: rows outside the window and K-padding channels must stay finite zeros
-  for (int i = tid; i < (R * rowbytes) >> 4; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < (R * rowbytes) >> 4; i += NTH) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   // x residual stream and skip sum of this wave's channels live in registers for the whole stack
   f32x4 xr[FW][NF], outr[FW][ON];
@@ -720,10 +723,10 @@ __global__ __launch_bounds__(256) void wn_stack_kernel(const WnStackArgs a) {
     // fused `pre` 1x1 (modules.py:212): stage the z slice of the window into the (still unused) acts tile,
     // one small GEMM, and the result IS the residual stream -- no launch, no round trip through memory
     const int pcpr = a.pre_KS * 4;                              // 16-byte chunks per staged row
-    for (int i = tid; i < (NB * rowbytes) >> 4; i += 256) reinterpret_cast<uint4*>(acts)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < (NB * rowbytes) >> 4; i += NTH) reinterpret_cast<uint4*>(acts)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const float* zb = a.z + (size_t)b * a.z_bs + a.pre_c0;
-    for (int idx = tid; idx < NB * pcpr; idx += 256) {
+    for (int idx = tid; idx < NB * pcpr; idx += NTH) {
       const int r = idx / pcpr, c8 = idx - r * pcpr;
       const int q = w0 + r;
       if (q >= 0 && q < a.T && c8 * 8 < a.pre_cin) {
@@ -1114,13 +1117,25 @@ int launch_pair_typed(const ConvDesc& d, const PairArgs& a, int batch, void* str
 }
 
 // ---- fused WaveNet layer dispatch
-template <typename T, int FW, int NF>
-inline int launch_wn_one(const WnArgs& a, int batch, hipStream_t stream) {
+inline int wn_wave_bucket(int waves) { return waves <= 4 ? 4 : (waves <= 8 ? 8 : (waves <= 12 ? 12 : 16)); }
+
+template <typename T, int NF, int WV>
+inline int launch_wn_one(const WnArgs& a, int waves, int batch, hipStream_t stream) {
   const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
-  dim3 grid((unsigned)ceil_div(a.T, NF * 16), (unsigned)batch);
-  if (a.last) hipLaunchKernelGGL((wn_layer_kernel<T, FW, NF, true>), grid, dim3(256), lds, stream, a);
-  else hipLaunchKernelGGL((wn_layer_kernel<T, FW, NF, false>), grid, dim3(256), lds, stream, a);
+  dim3 grid((unsigned)ceil_div(a.T, NF * 16), (unsigned)batch), block((unsigned)waves * 64);
+  if (a.last) hipLaunchKernelGGL((wn_layer_kernel<T, NF, true, WV>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((wn_layer_kernel<T, NF, false, WV>), grid, block, lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+template <typename T, int NF>
+inline int launch_wn_nf(const WnArgs& a, int waves, int batch, hipStream_t stream) {
+  switch (wn_wave_bucket(waves)) {
+    case 4: return launch_wn_one<T, NF, 4>(a, waves, batch, stream);
+    case 8: return launch_wn_one<T, NF, 8>(a, waves, batch, stream);
+    case 12: return launch_wn_one<T, NF, 12>(a, waves, batch, stream);
+    default: return launch_wn_one<T, NF, 16>(a, waves, batch, stream);
+  }
 }
 
 template <typename T>
@@ -1130,25 +1145,14 @@ int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* strea
   const long blocks32 = (long)ceil_div(a.T, 32) * batch;
   const int NF = blocks32 >= 512 ? 4 : 2;
   if (nf_out) *nf_out = NF;
-  const int FW = din.MF / 2;
-  if (din.WM != 4 || din.nchunk != 1) return QVC_ERR_BAD_CONFIG;
-  switch (FW * 10 + NF) {
-    case 12: return launch_wn_one<T, 1, 2>(a, batch, stream);
-    case 14: return launch_wn_one<T, 1, 4>(a, batch, stream);
-    case 22: return launch_wn_one<T, 2, 2>(a, batch, stream);
-    case 24: return launch_wn_one<T, 2, 4>(a, batch, stream);
-    case 32: return launch_wn_one<T, 3, 2>(a, batch, stream);
-    case 34: return launch_wn_one<T, 3, 4>(a, batch, stream);
-    case 42: return launch_wn_one<T, 4, 2>(a, batch, stream);
-    case 44: return launch_wn_one<T, 4, 4>(a, batch, stream);
-    default: return QVC_ERR_BAD_CONFIG;
-  }
+  if (!wn_layout_ok(din)) return QVC_ERR_BAD_CONFIG;
+  return NF == 4 ? launch_wn_nf<T, 4>(a, din.WM, batch, stream) : launch_wn_nf<T, 2>(a, din.WM, batch, stream);
 }
 
 // ---- whole-stack WaveNet dispatch
-template <typename T, int FW, int NF, int PM>
-inline int launch_wn_stack_pm(const WnStackArgs& a, int batch, hipStream_t stream) {
-  auto kern = wn_stack_kernel<T, FW, NF, PM>;
+template <typename T, int NF, int PM, int WV>
+inline int launch_wn_stack_pm(const WnStackArgs& a, int waves, int batch, hipStream_t stream) {
+  auto kern = wn_stack_kernel<T, NF, PM, WV>;
   const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1156,33 +1160,29 @@ inline int launch_wn_stack_pm(const WnStackArgs& a, int batch, hipStream_t strea
       return QVC_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, kWnOutFrames), (unsigned)batch), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, kWnOutFrames), (unsigned)batch), dim3((unsigned)waves * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
-template <typename T, int FW, int NF>
-inline int launch_wn_stack_one(const WnStackArgs& a, int batch, hipStream_t stream) {
-  const int pm = a.w_post ? a.post_mf : 0;
-  if (pm == 0) return launch_wn_stack_pm<T, FW, NF, 0>(a, batch, stream);
-  if (pm == 1) return launch_wn_stack_pm<T, FW, NF, 1>(a, batch, stream);
-  if (pm == 2) return launch_wn_stack_pm<T, FW, NF, 2>(a, batch, stream);
-  return QVC_ERR_BAD_CONFIG;
+template <typename T, int NF, int PM>
+inline int launch_wn_stack_wv(const WnStackArgs& a, int waves, int batch, hipStream_t stream) {
+  switch (wn_wave_bucket(waves)) {
+    case 4: return launch_wn_stack_pm<T, NF, PM, 4>(a, waves, batch, stream);
+    case 8: return launch_wn_stack_pm<T, NF, PM, 8>(a, waves, batch, stream);
+    case 12: return launch_wn_stack_pm<T, NF, PM, 12>(a, waves, batch, stream);
+    default: return launch_wn_stack_pm<T, NF, PM, 16>(a, waves, batch, stream);
+  }
 }
 
 template <typename T>
 int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (!wn_stack_ok(din, a.layers)) return QVC_ERR_BAD_CONFIG;
-  const int nf = wn_stack_nf(a.taps, a.layers), fw = din.MF / 2;
-  switch (fw * 10 + nf) {
-    case 13: return launch_wn_stack_one<T, 1, 3>(a, batch, stream);
-    case 16: return launch_wn_stack_one<T, 1, 6>(a, batch, stream);
-    case 23: return launch_wn_stack_one<T, 2, 3>(a, batch, stream);
-    case 26: return launch_wn_stack_one<T, 2, 6>(a, batch, stream);
-    case 33: return launch_wn_stack_one<T, 3, 3>(a, batch, stream);
-    case 36: return launch_wn_stack_one<T, 3, 6>(a, batch, stream);
-    default: return QVC_ERR_BAD_CONFIG;
-  }
+  const int nf = wn_stack_nf(a.taps, a.layers);
+  const int pm = a.w_post ? a.post_mf : 0;
+  if (pm > 1) return QVC_ERR_BAD_CONFIG;
+  if (nf == 3) return pm ? launch_wn_stack_wv<T, 3, 1>(a, din.WM, batch, stream) : launch_wn_stack_wv<T, 3, 0>(a, din.WM, batch, stream);
+  return pm ? launch_wn_stack_wv<T, 6, 1>(a, din.WM, batch, stream) : launch_wn_stack_wv<T, 6, 0>(a, din.WM, batch, stream);
 }
 
 }  // namespace qvc

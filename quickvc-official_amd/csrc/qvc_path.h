@@ -42,7 +42,9 @@ struct Path {
   }
   void conv(const ConvDesc& d, const ConvArgs& a, int epi = EPI_STD) {
     if (status != QVC_OK) return;
-    status = be.conv(d, a, B, epi, dtype());
+    const ConvDesc g = generic_layout(d);
+    ConvArgs ga = a; ga.nchunk = g.nchunk;
+    status = be.conv(g, ga, B, epi, dtype());
   }
   void zero(int64_t off, int64_t bytes) {
     if (status != QVC_OK) return;

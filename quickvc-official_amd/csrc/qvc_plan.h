@@ -108,20 +108,38 @@ inline void wide_pair_layout(ConvDesc& d1, ConvDesc& d2) {
   if (pair_supported(a, b)) { d1 = a; d2 = b; }
 }
 
+// WaveNet kernels (fused layer / whole stack): ONE WAVE PER 16 CHANNELS -- a workgroup of CinP/16 waves (12 at
+// h = 192) owns all channels of its frames.  A wave pulls global_load_dwordx4 data at only ~7.5 B/clk (measured:
+// 4 waves stream 28-30 B/clk per CU, 8 waves ~60, the L1's 64 B/clk), and these layers are bound by exactly that
+// weight stream (885 KB per layer into every CU), so the rows are spread over as many waves as there are row
+// fragments instead of 4 waves x 3 fragments.
+inline int wn_waves(int CinP) { return CinP / 16; }
+inline void wn_layout(ConvDesc& d, int mf) { d.WM = wn_waves(d.CinP); d.MF = mf; d.nchunk = 1; }
+// A plain conv packed one fragment per wave for W waves (a coupling layer's pre / post) is byte-identical to the
+// generic conv kernel's 4 waves x W/4 chunks: the stream is ordered by (chunk*WM + wave) either way.
+inline ConvDesc generic_layout(ConvDesc d) {
+  if (!d.gau && d.MF == 1 && d.nchunk == 1 && d.WM > kWaves && d.WM % kWaves == 0) { d.nchunk = d.WM / kWaves; d.WM = kWaves; }
+  return d;
+}
+inline bool wn_layout_ok(const ConvDesc& din) {
+  return din.gau && din.MF == 2 && din.nchunk == 1 && din.WM == wn_waves(din.CinP) && din.WM >= 1 && din.WM <= 16 &&
+         din.M == 2 * din.Cin;
+}
+
 // Whole-stack WaveNet kernel: window = 32 output frames + halo, built for 3 or 6 column fragments.
 inline int wn_stack_nf(int taps, int layers) { return ceil_div(32 + (taps - 1) * layers, 16); }
 inline bool wn_stack_ok(const ConvDesc& din, int layers) {
   const int nf = wn_stack_nf(din.taps, layers);
-  const int fw = din.MF / 2;
   const int halo = (din.taps - 1) / 2 * layers;                  // output frames = window columns [halo, halo+32)
   const bool cols_ok = nf == 3 || (nf == 6 && halo >= 16 && halo + 32 <= 64);   // fragments 1..3 hold the skip sum when nf == 6
-  return din.gau && din.WM == 4 && din.nchunk == 1 && layers <= 16 && (nf == 3 || nf == 6) && cols_ok && fw >= 1 && fw <= 3;
+  return wn_layout_ok(din) && layers <= 16 && cols_ok;
 }
 
-// Can a coupling layer's pre / post 1x1 convs ride inside its whole-stack launch?
+// Can a coupling layer's pre / post 1x1 convs ride inside its whole-stack launch?  (they must share the stack's
+// wave <-> channel ownership: pre's rows = the residual-stream rows, post reads the skip sum)
 inline bool wn_fuse_ok(const ConvDesc& din, const ConvDesc& pre, const ConvDesc& post, int layers) {
-  return wn_stack_ok(din, layers) && pre.WM == kWaves && pre.MF == din.MF / 2 && pre.nchunk == 1 && pre.CinP <= din.CinP &&
-         post.WM == kWaves && post.nchunk == 1 && (post.MF == 1 || post.MF == 2) && post.CinP == din.CinP;
+  return wn_stack_ok(din, layers) && pre.WM == din.WM && pre.MF == 1 && pre.nchunk == 1 && pre.CinP <= din.CinP &&
+         post.WM == din.WM && post.nchunk == 1 && post.MF == 1 && post.CinP == din.CinP;
 }
 
 struct WNPlan {
@@ -172,7 +190,7 @@ inline int validate(const qvc_config& c) {
   auto bad = [](bool cond) { return cond; };
   if (bad(c.unit_channels <= 0 || c.inter_channels <= 0 || c.hidden_channels <= 0 || c.gin_channels <= 0)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.inter_channels % 8 || c.hidden_channels % 8 || c.unit_channels % 8)) return QVC_ERR_BAD_CONFIG;
-  if (bad(c.hidden_channels > 256 || c.gin_channels % 4 || c.gin_channels > 512)) return QVC_ERR_BAD_CONFIG;   // one workgroup owns all WN channels (4 waves x 4 x 16)
+  if (bad(c.hidden_channels > 256 || c.gin_channels % 4 || c.gin_channels > 512)) return QVC_ERR_BAD_CONFIG;   // one workgroup owns all WN channels (up to 16 waves x 16 channels)
   if (bad(c.wn_kernel_size < 1 || c.wn_kernel_size % 2 == 0 || c.wn_kernel_size > 15)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.enc_layers < 1 || c.enc_layers > 64 || c.flow_layers < 1 || c.flow_layers > 64)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.n_flows < 1 || c.n_flows > 16 || c.n_flows % 2)) return QVC_ERR_BAD_CONFIG;   // flips must cancel
@@ -230,12 +248,13 @@ inline Plan build_plan(const qvc_config& c) {
     w.layers = layers;
     for (int i = 0; i < layers; ++i) {
       ConvDesc a = make_conv(2 * H, H, K, 1, /*gau=*/true);
+      wn_layout(a, 2);
       place(a, /*with_bias=*/false);
       w.in_conv.push_back(a);
       // 1x1 res/skip: rows paired like the gate rows ([res | skip] of the same channels per wave) so
       // that the fused layer kernel updates x and the skip accumulator for the channels it owns
       ConvDesc r = make_conv(i < layers - 1 ? 2 * H : H, H, 1, 1, /*gau=*/i < layers - 1);
-      if (i == layers - 1) { r.MF = a.MF / 2; r.WM = kWaves; r.nchunk = 1; }
+      wn_layout(r, i < layers - 1 ? 2 : 1);
       place(r);
       w.rs_conv.push_back(r);
     }
@@ -255,14 +274,20 @@ inline Plan build_plan(const qvc_config& c) {
     f.flipped = flipped ? 1 : 0;
     f.in_c0 = flipped ? C / 2 : 0;
     f.out_c0 = flipped ? 0 : C / 2;
-    // pre / post share the WaveNet kernels' channel ownership (4 waves along M) so that they can run inside
-    // the whole-stack launch: pre's rows = the stack's residual-stream rows, post reads the skip sum
+    // pre / post share the WaveNet kernels' channel ownership (one wave per 16 channels) when they can run
+    // inside the whole-stack launch: pre's rows = the stack's residual-stream rows, post reads the skip sum;
+    // otherwise they keep the generic conv layout and run as launches of their own
     f.pre = make_conv(H, C / 2, 1, 1);
-    f.pre.WM = kWaves; f.pre.MF = ceil_div(ceil_div(H, 16), kWaves); f.pre.nchunk = 1;
+    f.post = make_conv(C / 2, H, 1, 1);
+    {
+      ConvDesc probe = make_conv(2 * H, H, K, 1, /*gau=*/true);
+      wn_layout(probe, 2);
+      const bool fuse = wn_stack_ok(probe, c.flow_layers) && f.pre.CinP <= probe.CinP && ceil_div(C / 2, 16) <= probe.WM &&
+                        probe.WM % kWaves == 0;   // so that generic_layout() can still run them unfused
+      if (fuse) { f.pre.WM = probe.WM; f.pre.MF = 1; f.pre.nchunk = 1; f.post.WM = probe.WM; f.post.MF = 1; f.post.nchunk = 1; }
+    }
     place(f.pre);
     make_wn(f.wn, c.flow_layers);
-    f.post = make_conv(C / 2, H, 1, 1);
-    f.post.WM = kWaves; f.post.MF = ceil_div(ceil_div(C / 2, 16), kWaves); f.post.nchunk = 1;
     place(f.post);
     f.cond_row0 = cond_rows; cond_rows += c.flow_layers * 2 * H;
     P.flow.push_back(f);

@@ -190,23 +190,29 @@ def test_infer_api_matches_reference_semantics(lib, dev):
     assert snr_db(2.0 * spk["infer_o"], o2.cpu().numpy()) >= 45.0
 
 
-def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev):
-    """B=32, T=250 takes the whole-stack WaveNet kernel (16 / 4 layers per launch, overlap-tiled); a small
-    batch of the same utterances takes one launch per layer.  Same K order per frame -> identical results."""
+def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev, monkeypatch):
+    """The whole-stack WaveNet kernel (4 layers per launch, overlap-tiled, coupling pre/post fused) against the
+    path for configurations it does not cover -- one fused launch per layer, pre / post as separate convs --
+    selected with QVC_WN_CHUNK=-1.  Same K order per frame -> identical results."""
     from quickvc_official_amd.synth import make_synthetic_inputs
     entry, _ = load_case("full_b1")
     _m, sd, _u, _g, _n = regenerate(entry)
     eng = _engine(entry, sd, dev, "f16")
-    unit, g, noise = make_synthetic_inputs(32, 250, 256, 192, 256, seed0=300)
-    z_big = eng.enc_p(unit, noise)
+    unit, g, noise = make_synthetic_inputs(6, 250, 256, 192, 256, seed0=300)
+    z_stack = eng.enc_p(unit, noise)
+    zf_stack = eng.flow_reverse(z_stack, g)
     _, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
-    assert sum(r["name"].startswith("wn_stack<") for r in recs) == 8      # enc_p: 4 launches of 4 layers; 4 flows
-    z_small = eng.enc_p(unit[:2], noise[:2])
+    assert sum(r["name"].startswith("wn_stack<f16,W12,L4") for r in recs) == 8      # enc_p: 4 launches of 4 layers; 4 flows
+    monkeypatch.setenv("QVC_WN_CHUNK", "-1")
+    z_layer = eng.enc_p(unit, noise)
+    zf_layer = eng.flow_reverse(z_stack, g)
+    _, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
     torch.cuda.synchronize()
-    assert snr_db(z_small.cpu(), z_big[:2].cpu()) >= 100.0
-    zf_big = eng.flow_reverse(z_big, g)
-    zf_small = eng.flow_reverse(z_big[:2], g[:2])
-    assert snr_db(zf_small.cpu(), zf_big[:2].cpu()) >= 100.0
+    names = [r["name"] for r in recs]
+    assert sum(n.startswith("wn_layer<f16,W12") for n in names) == 32 and not any(n.startswith("wn_stack<") for n in names)
+    assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2 + 1      # + 4 x (pre, post)
+    assert snr_db(z_layer.cpu(), z_stack.cpu()) >= 100.0
+    assert snr_db(zf_layer.cpu(), zf_stack.cpu()) >= 100.0
 
 
 def test_hipgraph_capture_replays_identically(lib, dev):
@@ -238,11 +244,10 @@ def test_timed_variant_reports_every_launch(lib, dev):
     assert torch.equal(out, ref)
     names = [r["name"] for r in recs]
     assert names.count("istft_synth") == 1 and names.count("cond_gemv") == 1
-    # enc: pre + proj; flow: 4 x (pre + post); dec: conv_pre + 2 ups + conv_post; 16 + 4x4 fused WN layers;
-    # 2 x 9 fused ResBlock pairs
-    assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2 + 1
-    # mini B=2, T=12: too few tiles for the whole-stack kernel -> one launch per WaveNet layer
-    assert sum(n.startswith("wn_layer<") for n in names) == 32
+    # enc: pre + proj; dec: conv_pre + 2 ups + conv_post (the coupling layers' pre / post ride in their stack launch);
+    # enc_p WaveNet: 4 launches of 4 layers; 4 coupling stacks; 2 x 9 fused ResBlock pairs
+    assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 1
+    assert sum(n.startswith("wn_stack<") for n in names) == 8 and sum(n.startswith("wn_layer<") for n in names) == 0
     assert sum(n.startswith("rbpair<") for n in names) == 18
     assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0
 
@@ -271,10 +276,10 @@ def test_chunked_streaming_is_exact(lib, dev):
 
 
 def test_wide_config_takes_the_fallback_paths(lib, dev):
-    """A config the fused kernels do not cover: stage-1 ResBlocks 416 channels wide (two M chunks -> the
-    conv1 / conv2 launches with an operand-type residual instead of the fused pair), WaveNet width 256
-    (4 fragments per wave -> per-layer kernel, coupling pre/post as separate launches).  Checked against
-    the CPU oracle only (no golden: the reference was not run on this config)."""
+    """A config the fused pair kernel does not cover: stage-1 ResBlocks 416 channels wide (two M chunks -> the
+    conv1 / conv2 launches with an operand-type residual instead of the fused pair); WaveNet width 256 = the
+    widest the WaveNet kernels take (16 waves per workgroup).  Checked against the CPU oracle only (no golden:
+    the reference was not run on this config)."""
     import quickvc_official_amd as q
     from quickvc_official_amd.engine import QvcEngine
     from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_inputs
@@ -288,8 +293,8 @@ def test_wide_config_takes_the_fallback_paths(lib, dev):
     torch.cuda.synchronize()
     names = [r["name"] for r in recs]
     assert sum(n.startswith("rbpair<") for n in names) == 9           # stage 2 (208 channels) still fuses
-    assert sum(n.startswith("wn_layer<f16,FW4") for n in names) == 32
-    assert sum(n.startswith("conv<") for n in names) == 2 + 8 + 1 + 2 + 1 + 18   # + 9 x (conv1, conv2) of stage 1
+    assert sum(n.startswith("wn_stack<f16,W16") for n in names) == 8
+    assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 1 + 18   # + 9 x (conv1, conv2) of stage 1
     for b in range(2):
         assert snr_db(ref[b], out[b].cpu()) >= 45.0
 

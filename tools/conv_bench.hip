@@ -104,6 +104,7 @@ int main(int argc, char** argv) {
   {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
     const int H = 192, T = 250, L = 16;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
+    wn_layout(din, 2); wn_layout(drs, 2);
     din.w_off = 0; drs.w_off = align_up(din.w_bytes(), 256); drs.b_off = drs.w_off + align_up(drs.w_bytes(), 256);
     const size_t per = drs.b_off + align_up(drs.b_bytes(), 256);
     std::vector<char> hw(per * L, 0);
@@ -123,12 +124,13 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps / L;
     const double flops = 2.0 * B * T * (double)H * (2.0 * H * 5 + 2.0 * H);
-    printf("%-14s FW%d NF%-2d               %8.1f us/layer  %7.1f TF  (%.1f%% of 2.5PF)\n", "wn layer x16", din.MF / 2, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
+    printf("%-14s W%-2d NF%-2d               %8.1f us/layer  %7.1f TF  (%.1f%% of 2.5PF)\n", "wn layer x16", din.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
   {  // ---- whole-stack WaveNet launches: 4 layers per launch, 8 distinct weight sets (cold weights)
     const int H = 192, T = 250, L = 4, SETS = 8;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
+    wn_layout(din, 2); wn_layout(drs, 2);
     din.w_off = 0; drs.w_off = align_up(din.w_bytes(), 256); drs.b_off = drs.w_off + align_up(drs.w_bytes(), 256);
     const size_t per = drs.b_off + align_up(drs.b_bytes(), 256);
     std::vector<char> hw(per * L * SETS, 0);
@@ -149,7 +151,7 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps / (SETS * L);
     const double flops = 2.0 * B * T * (double)H * (2.0 * H * 5 + 2.0 * H);
-    printf("%-14s FW3 L4                 %8.1f us/layer  %7.1f TF\n", "wn stack", us, flops / us * 1e-6);
+    printf("%-14s W%-2d L4                 %8.1f us/layer  %7.1f TF\n", "wn stack", din.WM, us, flops / us * 1e-6);
     CK(hipFree(dw));
   }
   // ---- fused ResBlock pairs
