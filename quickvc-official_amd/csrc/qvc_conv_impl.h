@@ -102,18 +102,23 @@ __device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, f
 #define QVC_PF_WN 3
 #endif
 
-// The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
-// wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
-// The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
-// wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
-// A fragments go through a register ring, prefetched kPF k-steps ahead with plain loads (hipcc tracks
-// them).  An inline-asm variant with hand-counted vmcnt waits was tried and rejected: no faster, and
-// the compiler copied not-yet-landed asm outputs in one instantiation (wrong results).
+// gemm_prime issues the first kPF k-steps of a stream into the ring; gemm_loop_primed runs the K loop on a ring
+// primed that way.  (Priming the NEXT GEMM's ring before the epilogue and barrier of the current one was tried
+// in the WaveNet stack kernel -- 8 short GEMMs per launch -- and bought nothing: 14.3 vs 14.1 us per layer.)
+template <typename T, int MF, int kPF>
+__device__ __forceinline__ void gemm_prime(typename Op<T>::frag (&ar)[kPF + 1][MF], const typename Op<T>::frag* ap, int nIt) {
+#pragma unroll
+  for (int u = 0; u < kPF; ++u)
+    if (u < nIt) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)u * MF + m) * 64];
+    }
+}
+
 template <typename T, int MF, int NF, int kPF>
-__device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
-                                          const char* tile, int rowbytes, Swz sm, int colrow, int lq, int rot) {
-  // `rot`: optional rotated start of the walk over the k-steps (QVC_ROTATE, off by default)
-  //
+__device__ __forceinline__ void gemm_loop_primed(f32x4 (&acc)[MF][NF], typename Op<T>::frag (&ar)[kPF + 1][MF],
+                                                 const typename Op<T>::frag* ap, int nIt, int KS, int dil,
+                                                 const char* tile, int rowbytes, Swz sm, int colrow, int lq) {
   // Software pipeline (all register indices static after unrolling RING = kPF+1 steps, RING even):
   //   A fragments: global -> register ring, kPF k-steps ahead (plain loads, hipcc counts them);
   //   B fragments: LDS -> a double buffer, ONE k-step ahead.  Left to itself hipcc keeps two
@@ -124,25 +129,16 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
   using frag = typename O::frag;
   constexpr int RING = kPF + 1;
   static_assert(RING % 2 == 0, "the B double buffer needs an even ring");
-  frag ar[RING][MF];
   frag bf[2][NF];
   const int nstride = 16 * rowbytes;
-  int pf = rot;                                                 // physical k-step of the next A prefetch
-#pragma unroll
-  for (int u = 0; u < kPF; ++u)
-    if (u < nIt) {
-#pragma unroll
-      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)pf * MF + m) * 64];
-      if (++pf == nIt) pf = 0;
-    }
-  int tap = rot / KS, ks = rot - tap * KS;                      // k-step whose B fragments are read next
+  int pf = kPF < nIt ? kPF : nIt;                               // k-step of the next A prefetch (== nIt: none left)
+  int tap = 0, ks = 0;                                          // k-step whose B fragments are read next
   auto read_b = [&](frag (&dst)[NF]) {
     const int row0 = tap * dil + colrow;
     const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
 #pragma unroll
     for (int n = 0; n < NF; ++n) dst[n] = *reinterpret_cast<const frag*>(bp + n * nstride);
     if (++ks == KS) { ks = 0; ++tap; }
-    if (tap * KS + ks == nIt) { tap = 0; ks = 0; }
   };
   if (nIt > 0) read_b(bf[0]);
   for (int it0 = 0; it0 < nIt; it0 += RING) {
@@ -153,7 +149,7 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
         if (it + kPF < nIt) {
 #pragma unroll
           for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pf * MF + m) * 64];
-          if (++pf == nIt) pf = 0;
+          ++pf;
         }
         if (it + 1 < nIt) read_b(bf[(u + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);                      // loads stay above this step's MFMAs
@@ -165,6 +161,19 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
       }
     }
   }
+}
+
+// The K loop shared by the kernels: acc[m][n] += A(stream) x B(LDS tile).  `ap` already points at this
+// wave's fragment stream (+lane); B rows start at `colrow` (+ tap*dil); rows are `rowbytes` wide.
+// A fragments go through a register ring, prefetched kPF k-steps ahead with plain loads (hipcc tracks
+// them).  An inline-asm variant with hand-counted vmcnt waits was tried and rejected: no faster, and
+// the compiler copied not-yet-landed asm outputs in one instantiation (wrong results).
+template <typename T, int MF, int NF, int kPF>
+__device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
+                                          const char* tile, int rowbytes, Swz sm, int colrow, int lq, int /*rot*/) {
+  typename Op<T>::frag ar[kPF + 1][MF];
+  gemm_prime<T, MF, kPF>(ar, ap, nIt);
+  gemm_loop_primed<T, MF, NF, kPF>(acc, ar, ap, nIt, KS, dil, tile, rowbytes, sm, colrow, lq);
 }
 
 // WM waves along M, WN = 4/WM along the frames; block tile = [WM*MF*16 rows] x [WN*NF*16 frames].
