@@ -16,6 +16,9 @@ struct Shape { const char* name; int Cin, M, T, k, dil; int kind; /*0 std f32 in
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 32;
   const int reps = argc > 2 ? atoi(argv[2]) : 20;
+  // QVC_BENCH_ZEROS=1: all-zero activations and weights -- same instruction stream and cycles, but the chip holds a
+  // higher clock on zero operands (DVFS), so the ratio to the random-data run is the clock given back under load
+  const bool zeros = getenv("QVC_BENCH_ZEROS") != nullptr;
   std::vector<Shape> shapes = {
     {"s2 c1 k3 d1", 128, 128, 5000, 3, 1, 0}, {"s2 c1 k7 d3", 128, 128, 5000, 7, 3, 0}, {"s2 c1 k11 d5", 128, 128, 5000, 11, 5, 0},
     {"s2 c2 k3", 128, 128, 5000, 3, 1, 1}, {"s2 c2 k11", 128, 128, 5000, 11, 1, 1},
@@ -30,11 +33,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&x16, maxel * 2)); CK(hipMalloc(&y16, maxel * 2)); CK(hipMalloc(&bb, 1 << 20));
   {
     std::vector<float> h(maxel);
-    for (size_t i = 0; i < maxel; ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 32768.f - 1.f;
+    for (size_t i = 0; i < maxel; ++i) h[i] = zeros ? 0.f : (float)((i * 2654435761u >> 8) & 0xffff) / 32768.f - 1.f;
     CK(hipMemcpy(x32, h.data(), maxel * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(res, h.data(), maxel * 4, hipMemcpyHostToDevice));
     std::vector<uint16_t> hh(maxel);
-    for (size_t i = 0; i < maxel; ++i) hh[i] = (uint16_t)(0x3000 + ((i * 40503u) & 0x7ff) + ((i & 1) << 15));   // small f16 values
+    for (size_t i = 0; i < maxel; ++i) hh[i] = zeros ? 0 : (uint16_t)(0x3000 + ((i * 40503u) & 0x7ff) + ((i & 1) << 15));   // small f16 values
     CK(hipMemcpy(x16, hh.data(), maxel * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bb, 0, 1 << 20));
   }
@@ -45,7 +48,7 @@ int main(int argc, char** argv) {
     size_t wb = d.b_off + d.b_bytes();
     std::vector<char> hw(wb);
     std::vector<float> w((size_t)s.M * s.Cin * s.k), bias(s.M, 0.01f);
-    for (size_t i = 0; i < w.size(); ++i) w[i] = ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
+    for (size_t i = 0; i < w.size(); ++i) w[i] = zeros ? 0.f : ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
     pack_plain_conv(d, w.data(), bias.data(), QVC_F16, hw.data());
     void* dw; CK(hipMalloc(&dw, wb)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
     ConvArgs a;
@@ -166,7 +169,7 @@ int main(int argc, char** argv) {
     size_t wb = d1.b_off + d1.b_bytes();
     std::vector<char> hw(wb);
     std::vector<float> w((size_t)s.C * s.C * s.k), bias(s.C, 0.01f);
-    for (size_t i = 0; i < w.size(); ++i) w[i] = ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
+    for (size_t i = 0; i < w.size(); ++i) w[i] = zeros ? 0.f : ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
     pack_plain_conv(d1, w.data(), bias.data(), QVC_F16, hw.data());
     void* dw; CK(hipMalloc(&dw, wb)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
     PairArgs a;
