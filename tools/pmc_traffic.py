@@ -32,12 +32,12 @@ def pretty(name):
     m = re.search(r"conv_mfma_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"conv<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)},{'gau' if m.group(5) == '1' else 'std'}>"
-    m = re.search(r"wn_stack_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)E", name)
+    m = re.search(r"wn_stack_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
-        return f"wn_stack<{'f16' if m.group(1) == 'DF16_' else 'bf16'},FW{m.group(2)},NF{m.group(3)}>"
-    m = re.search(r"wn_layer_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELb(\d)E", name)
+        return f"wn_stack<{'f16' if m.group(1) == 'DF16_' else 'bf16'},W{m.group(4)},L4{',pre+post' if m.group(3) != '0' else ''}>"
+    m = re.search(r"wn_layer_kernelI(DF16_|DF16b)Li(\d+)ELb(\d)ELi(\d+)E", name)
     if m:
-        return f"wn_layer<{'f16' if m.group(1) == 'DF16_' else 'bf16'},FW{m.group(2)},NF{m.group(3)}{',last' if m.group(4) == '1' else ''}>"
+        return f"wn_layer<{'f16' if m.group(1) == 'DF16_' else 'bf16'},W{m.group(4)},NF{m.group(2)}{',last' if m.group(3) == '1' else ''}>"
     return re.sub(r"\(.*", "", name).replace("qvc::", "")
 
 
