@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 2
+#define QVC_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -220,6 +220,25 @@ int64_t qvc_spk_workspace_bytes(const qvc_config* cfg, int32_t utterances, int32
 int qvc_speaker_embed(const qvc_config* cfg, const void* spk_blob_dev, const float* mel, float* g,
                       int32_t utterances, int32_t mel_frames,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- mel front-end: replaces mel_processing.wave_to_mel (mel_processing.py:15-98) ---------
+ * The step in front of the speaker encoder on the target side (convert.py:75-77):
+ * reflect pad (n_fft-hop)/2, Hann STFT (center=False, win = n_fft), sqrt(re^2+im^2+1e-6),
+ * mel-basis matmul, log(clamp(., 1e-5)).  All fp32: the STFT is a GEMM against a windowed DFT table
+ * on the f32 MFMA (bitwise an fmaf chain), so it needs no FFT plan and no complex temporaries.
+ *   wave (U, samples) fp32 in [-1, 1]   ->   mel (U, n_mels, frames) fp32,
+ *   frames = (samples + 2*((n_fft-hop)/2) - n_fft) / hop + 1.
+ * The mel filter bank itself is the caller's (n_mels x (n_fft/2+1), librosa.filters.mel in the
+ * reference): qvc_mel_pack_tables turns it and the windowed DFT matrix into the device table.
+ * Needs n_fft % 16 == 0, hop % 4 == 0, n_fft >= hop, samples > (n_fft-hop)/2.
+ */
+int64_t qvc_mel_table_bytes(int32_t n_fft, int32_t n_mels);
+int qvc_mel_pack_tables(int32_t n_fft, int32_t hop, int32_t n_mels, const float* mel_basis_host,
+                        void* table_host, int64_t table_bytes);
+int64_t qvc_mel_workspace_bytes(int32_t n_fft, int32_t hop, int32_t utterances, int32_t samples);
+int qvc_wave_to_mel(const void* table_dev, int32_t n_fft, int32_t hop, int32_t n_mels,
+                    const float* wave, float* mel, int32_t utterances, int32_t samples,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

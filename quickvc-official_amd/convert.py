@@ -26,7 +26,7 @@ import torch
 from .checkpoint import load_checkpoint
 from .dist import env_world, shard_indices
 from .config import get_hparams_from_file
-from .frontend import load_wav, trim, wave_to_mel
+from .frontend import MelFrontend, load_wav, trim, wave_to_mel
 from .model import SynthesizerTrn
 
 
@@ -93,11 +93,14 @@ def main(argv=None) -> None:
         # speaker embeddings once per distinct target (the reference recomputes them per line)
         g_cache = {}
         prepared = []
+        # mel front-end on the GPU (qvc_wave_to_mel) when the config has win == n_fft, else the torch restatement
+        front = MelFrontend(d.filter_length, d.n_mel_channels, d.sampling_rate, d.hop_length, d.win_length,
+                            d.mel_fmin, d.mel_fmax) if d.win_length == d.filter_length and d.hop_length % 16 == 0 else None
         for title, src, tgt in items:
             if tgt not in g_cache:
-                wav = trim(load_wav(tgt, d.sampling_rate), top_db=20)
-                mel = wave_to_mel(torch.from_numpy(wav).unsqueeze(0).cuda(), d.filter_length, d.n_mel_channels,
-                                  d.sampling_rate, d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
+                wav = torch.from_numpy(trim(load_wav(tgt, d.sampling_rate), top_db=20)).unsqueeze(0).cuda()
+                mel = front(wav) if front is not None else wave_to_mel(wav, d.filter_length, d.n_mel_channels, d.sampling_rate,
+                                                                       d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
                 g_cache[tgt] = net_g.speaker_embed(mel)                 # (1, 80, F') -> (1, gin), HIP LSTM
             prepared.append((title, _load_units(src), g_cache[tgt]))
         # this rank's shard of the list, then equal-length utterances share a launch

@@ -55,6 +55,57 @@ def wave_to_mel(wave: torch.Tensor, n_fft: int, n_mels: int, sr: int, hop: int, 
     return torch.log(torch.clamp(basis @ mag, min=1e-5))
 
 
+class MelFrontend:
+    """``wave_to_mel`` on the GPU through the C ABI (qvc_wave_to_mel, csrc/qvc_mel.hip): fp32 STFT as a GEMM
+    against a windowed DFT table on the f32 MFMA, magnitude, sparse mel filters, log -- two launches, no FFT plan.
+
+    Same arguments as mel_processing.wave_to_mel (win must equal n_fft, as in the shipped config); the mel filter
+    bank is ``mel_basis`` above (parity-unpinned against librosa, see the module docstring).
+    """
+
+    def __init__(self, n_fft: int, n_mels: int, sr: int, hop: int, win: int, fmin: float, fmax, device="cuda"):
+        import ctypes
+        from . import lib as L
+        if win != n_fft:
+            raise ValueError("the HIP front-end needs win_length == filter_length")
+        self.lib = L.load_library()
+        self.n_fft, self.hop, self.n_mels = int(n_fft), int(hop), int(n_mels)
+        self.device = torch.device(device)
+        basis = np.ascontiguousarray(mel_basis(sr, n_fft, n_mels, fmin, fmax), dtype=np.float32)
+        n = int(self.lib.qvc_mel_table_bytes(self.n_fft, self.n_mels))
+        if n < 0:
+            L.check(self.lib, n, "qvc_mel_table_bytes")
+        host = torch.empty(n, dtype=torch.uint8)
+        L.check(self.lib, self.lib.qvc_mel_pack_tables(self.n_fft, self.hop, self.n_mels, basis.ctypes.data_as(ctypes.c_void_p),
+                                                       host.data_ptr(), n), "qvc_mel_pack_tables")
+        self.table = host.to(self.device)
+        self._ws = None
+
+    def frames(self, samples: int) -> int:
+        pad = (self.n_fft - self.hop) // 2
+        return (samples + 2 * pad - self.n_fft) // self.hop + 1
+
+    @torch.no_grad()
+    def __call__(self, wave: torch.Tensor) -> torch.Tensor:
+        """wave (U, samples) in [-1, 1] -> log-mel (U, n_mels, frames) fp32 on the device."""
+        from . import lib as L
+        if wave.dim() != 2:
+            raise ValueError(f"wave must be (utterances, samples), got {tuple(wave.shape)}")
+        wave = wave.to(device=self.device, dtype=torch.float32).contiguous()
+        U, N = wave.shape
+        n = int(self.lib.qvc_mel_workspace_bytes(self.n_fft, self.hop, U, N))
+        if n < 0:
+            L.check(self.lib, n, "qvc_mel_workspace_bytes")
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        mel = torch.empty(U, self.n_mels, self.frames(N), dtype=torch.float32, device=self.device)
+        st = self.lib.qvc_wave_to_mel(self.table.data_ptr(), self.n_fft, self.hop, self.n_mels, wave.data_ptr(), mel.data_ptr(),
+                                      U, N, self._ws.data_ptr(), self._ws.numel(),
+                                      torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_wave_to_mel")
+        return mel
+
+
 def trim(wave: np.ndarray, top_db: float = 20.0, frame_length: int = 2048, hop_length: int = 512) -> np.ndarray:
     """Drop leading/trailing frames whose RMS is more than ``top_db`` below the peak frame."""
     if len(wave) < frame_length:

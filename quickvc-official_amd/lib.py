@@ -96,6 +96,14 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_spk_workspace_bytes.argtypes = [cfgp, I, I]
         lib.qvc_speaker_embed.restype = ctypes.c_int
         lib.qvc_speaker_embed.argtypes = [cfgp, V, V, V, I, I, V, L, V]
+        lib.qvc_mel_table_bytes.restype = L
+        lib.qvc_mel_table_bytes.argtypes = [I, I]
+        lib.qvc_mel_pack_tables.restype = ctypes.c_int
+        lib.qvc_mel_pack_tables.argtypes = [I, I, I, V, V, L]
+        lib.qvc_mel_workspace_bytes.restype = L
+        lib.qvc_mel_workspace_bytes.argtypes = [I, I, I, I]
+        lib.qvc_wave_to_mel.restype = ctypes.c_int
+        lib.qvc_wave_to_mel.argtypes = [V, I, I, I, V, V, I, I, V, L, V]
 
 
 _lib = None
@@ -110,7 +118,7 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 2:
+        if lib.qvc_abi_version() != 3:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -366,3 +366,24 @@ def test_speaker_embed_bad_args(lib, dev):
     st = eng.lib.qvc_speaker_embed(ctypes.byref(eng.cfg), eng._spk_blob.data_ptr(), None, g.data_ptr(), 1, 50,
                                    eng._spk_ws.data_ptr(), eng._spk_ws.numel(), None)
     assert st == -1      # QVC_ERR_BAD_ARG
+
+
+# ------------------------------------------------------------------ mel front-end
+@pytest.mark.parametrize("samples,U", [(80000, 2), (16000 * 3 + 123, 1), (2000, 3), (641, 1)])
+def test_wave_to_mel_matches_torch_restatement(lib, dev, samples, U):
+    """qvc_wave_to_mel (fp32 MFMA STFT + sparse mel + log) vs the torch restatement of mel_processing.py:15-98
+    in frontend.wave_to_mel run on the CPU (torch.stft, fp32), shipped front-end parameters (1280 / 320 / 80 mel).
+    Lengths: a multiple of the hop, a ragged one, one shorter than a window, the shortest the reflect pad allows.
+    Tolerance: |log-mel difference| <= 2e-5 (fp32 summation order of a 1280-term DFT vs the FFT's butterflies;
+    the clamp at 1e-5 bounds the log's sensitivity; measured 1.4e-6).  The mel filter bank itself is parity-unpinned (no librosa)."""
+    from quickvc_official_amd.frontend import MelFrontend, wave_to_mel
+    gen = torch.Generator().manual_seed(samples + U)
+    t = torch.arange(samples) / 16000.0
+    wave = 0.3 * torch.sin(2 * np.pi * 220.0 * t)[None] * torch.rand(U, 1, generator=gen) + 0.05 * torch.randn(U, samples, generator=gen)
+    wave = wave.clamp(-1, 1)
+    fe = MelFrontend(1280, 80, 16000, 320, 1280, 0.0, None, device=dev)
+    mel = fe(wave.to(dev))
+    torch.cuda.synchronize()
+    ref = wave_to_mel(wave, 1280, 80, 16000, 320, 1280, 0.0, None)
+    assert mel.shape == ref.shape == (U, 80, fe.frames(samples)) and mel.dtype == torch.float32
+    assert float((mel.cpu() - ref).abs().max()) <= 2e-5

@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "qvc.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
-    assert len(names) >= 18
+    assert len(names) >= 22
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 2
+    assert built.qvc_abi_version() == 3
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
 
 
@@ -111,6 +111,44 @@ def test_speaker_encoder_pack_and_host_emulation(built):
     cfg2 = L.make_config(dict(model.model_config)); cfg2.gin_channels = 320
     assert built.qvc_spk_blob_bytes(ctypes.byref(cfg2)) == -2
     assert built.qvc_spk_workspace_bytes(ctypes.byref(cfg), 0, 10) == -1
+
+
+def test_mel_table_packer(built):
+    """qvc_mel_pack_tables (host code): the windowed DFT table, unpacked with the kernel's index math, equals
+    hann[k] * cos / -sin(2 pi bin k / n_fft); filter ranges cover exactly the non-zero weights; error codes."""
+    from quickvc_official_amd.frontend import mel_basis
+    n_fft, hop, n_mels = 64, 16, 10
+    basis = np.ascontiguousarray(mel_basis(16000, n_fft, n_mels, 0.0, None), dtype=np.float32)
+    n = int(built.qvc_mel_table_bytes(n_fft, n_mels))
+    assert n > 0
+    tab = np.zeros(n, dtype=np.uint8)
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+    assert built.qvc_mel_pack_tables(n_fft, hop, n_mels, vp(basis), vp(tab), n) == 0
+    bins, ksteps, nchunk = n_fft // 2 + 1, n_fft // 16, 1
+    dft = tab[: nchunk * 4 * ksteps * 4 * 64 * 4 * 4].view(np.float32).reshape(nchunk, 4, ksteps, 4, 64, 4)
+    k = np.arange(n_fft)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * k / n_fft)
+    for w in range(4):
+        for m in range(4):
+            for lane in (0, 5, 17, 63):
+                b = w * 32 + (m >> 1) * 16 + (lane & 15)
+                for s_ in range(ksteps):
+                    kk = s_ * 16 + (lane >> 4) * 4 + np.arange(4)
+                    want = np.zeros(4) if b >= bins else (win[kk] * np.cos(2 * np.pi * b * kk / n_fft) if m % 2 == 0
+                                                          else -win[kk] * np.sin(2 * np.pi * b * kk / n_fft))
+                    assert np.abs(dft[0, w, s_, m, lane] - want).max() < 1e-6
+    off_basis = (dft.size * 4 + 255) // 256 * 256
+    got_basis = tab[off_basis: off_basis + n_mels * bins * 4].view(np.float32).reshape(n_mels, bins)
+    assert np.array_equal(got_basis, basis)
+    off_range = (off_basis + n_mels * bins * 4 + 255) // 256 * 256
+    rng = tab[off_range: off_range + n_mels * 8].view(np.int32).reshape(n_mels, 2)
+    for m in range(n_mels):
+        nz = np.nonzero(basis[m])[0]
+        assert rng[m, 0] == nz[0] and rng[m, 1] == nz[-1] + 1
+    assert built.qvc_mel_pack_tables(60, hop, n_mels, vp(basis), vp(tab), n) == -2        # n_fft % 16
+    assert built.qvc_mel_pack_tables(n_fft, hop, n_mels, vp(basis), vp(tab), 16) == -5    # small buffer
+    assert built.qvc_mel_workspace_bytes(n_fft, hop, 1, 10) == -1                         # shorter than the reflect pad
+    assert built.qvc_mel_workspace_bytes(n_fft, hop, 2, 1000) > 0
 
 
 def test_weight_norm_and_flip_folding_change_nothing(built):
