@@ -387,3 +387,55 @@ def test_wave_to_mel_matches_torch_restatement(lib, dev, samples, U):
     ref = wave_to_mel(wave, 1280, 80, 16000, 320, 1280, 0.0, None)
     assert mel.shape == ref.shape == (U, 80, fe.frames(samples)) and mel.dtype == torch.float32
     assert float((mel.cpu() - ref).abs().max()) <= 2e-5
+
+
+def test_convert_cli_end_to_end(lib, dev, tmp_path):
+    """BASELINE configs[0] plumbing on the GPU: the reference CLI surface (convert.py:19-86) from files to files --
+    JSON config, checkpoint in the reference's format, `title|src|tgt` list, target wav -> trim -> HIP mel ->
+    HIP speaker encoder, source units from .npy -> HIP path -> float32 wav of 320 samples per unit frame.
+    The written waveform must equal what the Python API computes from the same files and seed."""
+    import json
+    from scipy.io import wavfile
+    import quickvc_official_amd as q
+    from quickvc_official_amd import convert as cli
+    from quickvc_official_amd.checkpoint import save_checkpoint
+    from quickvc_official_amd.frontend import MelFrontend, load_wav, trim
+    from quickvc_official_amd.synth import make_synthetic_state_dict
+    cfg = {"train": {"segment_size": 10240}, "data": dict(q.DEFAULT_DATA_CONFIG), "model": dict(q.MINI_MODEL_CONFIG)}
+    hp = tmp_path / "config.json"
+    hp.write_text(json.dumps(cfg))
+    model = q.SynthesizerTrn(641, 32, **q.MINI_MODEL_CONFIG)
+    sd = make_synthetic_state_dict(model, 21)
+    model.load_state_dict(sd)
+    pt = tmp_path / "G_1.pth"
+    save_checkpoint(model, None, 2e-4, 1, str(pt))
+    sr = cfg["data"]["sampling_rate"]
+    t = np.arange(int(1.7 * sr)) / sr
+    tgt = (0.4 * np.sin(2 * np.pi * 180 * t) * (t > 0.2) * (t < 1.5)).astype(np.float32)      # silence to trim on both sides
+    wavfile.write(str(tmp_path / "tgt.wav"), sr, (tgt * 32767).astype(np.int16))
+    rng = np.random.RandomState(5)
+    for name, frames in (("a", 81), ("b", 81), ("c", 40)):
+        np.save(str(tmp_path / f"{name}.npy"), rng.randn(frames, 256).astype(np.float32))
+    (tmp_path / "convert.txt").write_text("".join(f"t_{n}|{tmp_path}/{n}.npy|{tmp_path}/tgt.wav\n" for n in "abc"))
+    out = tmp_path / "out"
+    cli.main(["--hpfile", str(hp), "--ptfile", str(pt), "--txtpath", str(tmp_path / "convert.txt"), "--outdir", str(out),
+              "--seed", "7", "--batch", "2"])
+    d = cfg["data"]
+    wav = torch.from_numpy(trim(load_wav(str(tmp_path / "tgt.wav"), sr), top_db=20)).unsqueeze(0)
+    assert wav.shape[1] < len(tgt)                                   # the silence was trimmed
+    mel = MelFrontend(d["filter_length"], d["n_mel_channels"], sr, d["hop_length"], d["win_length"], d["mel_fmin"], d["mel_fmax"])(wav)
+    net = model.cuda().eval()
+    g = net.speaker_embed(mel)
+    for name, frames in (("a", 81), ("b", 81), ("c", 40)):
+        rate, got = wavfile.read(str(out / f"t_{name}.wav"))
+        assert rate == sr and got.dtype == np.float32 and got.shape == (320 * frames,)     # convert.py:84-86
+        assert np.isfinite(got).all() and np.abs(got).max() > 0
+    # same seed, same batching (longest first: a and b share the first launch) -> identical noise draw
+    _, got_a = wavfile.read(str(out / "t_a.wav"))
+    matches = []
+    for order in ("ab", "ba"):
+        torch.manual_seed(7)
+        unit = torch.stack([torch.from_numpy(np.load(str(tmp_path / f"{n}.npy"))).t() for n in order], 0).cuda()
+        ref = net.infer_batch(unit, g.expand(2, -1))
+        matches.append(np.array_equal(got_a, ref[order.index("a"), 0].cpu().numpy()))
+    assert any(matches)
