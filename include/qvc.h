@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 3
+#define QVC_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -91,6 +91,7 @@ typedef struct qvc_config {
   int32_t fir_taps;                 /* 63: multistream_conv_post / PQMF taps+1           */
   int32_t operand_dtype;            /* QVC_BF16 / QVC_F16                                */
   int32_t n_mel_channels;           /* SpeakerEncoder input size (models.py:508); 0 = 80  */
+  int32_t spec_channels;            /* enc_q input size = filter_length/2+1 (convert.py:35); 0 = 641 */
 } qvc_config;
 
 /* One named fp32 tensor of the reference checkpoint's state_dict (utils.py:183-193). */
@@ -239,6 +240,29 @@ int64_t qvc_mel_workspace_bytes(int32_t n_fft, int32_t hop, int32_t utterances, 
 int qvc_wave_to_mel(const void* table_dev, int32_t n_fft, int32_t hop, int32_t n_mels,
                     const float* wave, float* mel, int32_t utterances, int32_t samples,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- posterior direction: enc_q and the forward flow (models.py:617-618) -------
+ * z ~ enc_q(spec | g) = CondNormalWN with speaker conditioning (models.py:75-95,582), then
+ * z_p = flow(z, g) = ResidualCouplingBlock.forward(reverse=False) (models.py:39-51; x1 <- m + x1,
+ * modules.py:217).  Not used by convert.py; it is the analysis half of the model (reconstruction /
+ * evaluation) and runs on the same WaveNet kernels.  enc_q has its own blob (state-dict keys enc_q.*);
+ * the forward flow reuses the path's blob: every coupling layer sees the same channel flip in both
+ * directions, so the flip-folded pre / post weights serve both.
+ *   spec  (B, spec_channels, T) fp32   linear spectrogram        (mel_processing.py:15-58)
+ *   g     (B, gin_channels)     fp32
+ *   noise (B, inter_channels, T) fp32  the N(0,1) draw of models.py:94
+ *   z_fm / z: frame-major [B][T][inter_channels] fp32 (as the stage entry points above)
+ * Both use the workspace of qvc_workspace_bytes(cfg, batch, frames).
+ */
+int64_t qvc_encq_blob_bytes(const qvc_config* cfg);
+int qvc_encq_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors, int32_t n_tensors,
+                          void* blob_host, int64_t blob_bytes);
+int qvc_enc_q(const qvc_config* cfg, const void* encq_blob_dev, const float* spec, const float* g,
+              const float* noise, float* z_fm, int32_t batch, int32_t frames,
+              void* workspace, int64_t workspace_bytes, void* stream);
+int qvc_flow_forward(const qvc_config* cfg, const void* blob_dev, float* z_fm, const float* g,
+                     int32_t batch, int32_t frames,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -266,7 +266,7 @@ struct EmuBackend {
       ConvArgs a; fill(a, *dpost);
       a.w = s.w_post; a.bias = s.b_post; a.x = out; a.x_kind = XK_F32_FM; a.x_bs = s.bs; a.x_ts = s.H;
       a.T_in = s.T; a.Nq = s.T; a.T_out = s.T;
-      a.res = s.z; a.res_bs = s.z_bs; a.res_ts = s.z_ts; a.res_c0 = s.post_c0; a.res_sign = -1.f;
+      a.res = s.z; a.res_bs = s.z_bs; a.res_ts = s.z_ts; a.res_c0 = s.post_c0; a.res_sign = s.post_sign;
       a.y32 = s.z; a.y32_bs = s.z_bs; a.y32_ts = s.z_ts; a.y32_c0 = s.post_c0;
       conv(*dpost, a, B, EPI_STD, dtype);
     }
@@ -446,6 +446,30 @@ int qvc_emu_infer_batch(const qvc_config* cfg, const void* blob, const float* un
   c.flow(c.wsp<float>(r.W.z));
   c.dec_trunk(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post));
   c.tail(c.wsp<float>(r.W.post), out, nullptr, frames * r.P.total_up + 1);
+  return c.status;
+}
+
+// Same signatures as qvc_enc_q / qvc_flow_forward, host pointers, no stream.
+int qvc_emu_enc_q(const qvc_config* cfg, const void* encq_blob, const float* spec, const float* g, const float* noise,
+                  float* z_fm, int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes) {
+  Run r;
+  int st = r.prepare(cfg, batch, frames, workspace_bytes);
+  if (st != QVC_OK) return st;
+  const EncQPlan Q = build_encq_plan(*cfg);
+  if (Q.status != QVC_OK) return Q.status;
+  Path<EmuBackend> c{r.P, static_cast<const char*>(encq_blob), static_cast<char*>(workspace), r.W, batch, frames, r.be};
+  c.enc_q(Q, static_cast<const char*>(encq_blob), spec, g, noise, z_fm);
+  return c.status;
+}
+
+int qvc_emu_flow_forward(const qvc_config* cfg, const void* blob, float* z_fm, const float* g, int32_t batch, int32_t frames,
+                         void* workspace, int64_t workspace_bytes) {
+  Run r;
+  int st = r.prepare(cfg, batch, frames, workspace_bytes);
+  if (st != QVC_OK) return st;
+  Path<EmuBackend> c{r.P, static_cast<const char*>(blob), static_cast<char*>(workspace), r.W, batch, frames, r.be};
+  c.cond_table(g);
+  c.flow(z_fm, /*forward=*/true);
   return c.status;
 }
 

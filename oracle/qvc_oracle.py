@@ -139,6 +139,42 @@ def flow_reverse(sd: State, z_p: Tensor, g: Tensor, channels: int, hidden: int, 
     return x
 
 
+def flow_forward(sd: State, z: Tensor, g: Tensor, channels: int, hidden: int, n_flows: int = 4,
+                 taps: Optional[dict] = None) -> Tensor:
+    """ResidualCouplingBlock.forward(reverse=False), models.py:39-51 (the posterior direction, models.py:618):
+    layer then Flip, for layers 0,2,4,6; the coupling adds: x1 <- m + x1 (modules.py:217)."""
+    half = channels // 2
+    x = z
+    for idx in range(n_flows):
+        p = f"flow.flows.{2 * idx}"
+        x0, x1 = x[:, :half], x[:, half:]
+        h = F.conv1d(x0, conv_weight(sd, f"{p}.pre"), conv_bias(sd, f"{p}.pre"))
+        h = wn_forward(sd, f"{p}.enc", h, g, hidden, 5, 4)
+        m = F.conv1d(h, conv_weight(sd, f"{p}.post"), conv_bias(sd, f"{p}.post"))
+        x = torch.cat([x0, m + x1], 1)
+        if taps is not None:
+            taps[f"{p}.fwd"] = x.clone()
+        x = torch.flip(x, [1])
+    return x
+
+
+def posterior_encode(sd: State, cfg: dict, spec: Tensor, g: Tensor, noise: Tensor,
+                     taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+    """The posterior half of SynthesizerTrn.forward, models.py:617-618: z ~ enc_q(spec | g), z_p = flow(z, g).
+
+    spec :: (B, spec_channels, T), g :: (B, gin, 1), noise :: (B, inter, T) -> (z, z_p)."""
+    sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()}
+    inter, hidden = int(cfg["inter_channels"]), int(cfg["hidden_channels"])
+    with torch.no_grad():
+        z, mu, logs = cond_normal_wn(sd, "enc_q", spec.float(), noise.float(), hidden, inter, g.float(), None)
+        if taps is not None:
+            taps["enc_q.m"], taps["enc_q.logs"], taps["enc_q.z"] = mu.clone(), logs.clone(), z.clone()
+        z_p = flow_forward(sd, z, g.float(), inter, hidden, 4, taps)
+        if taps is not None:
+            taps["flow.z_p"] = z_p.clone()
+    return z, z_p
+
+
 # --------------------------------------------------------------------------- decoder pieces
 def resblock1(sd: State, prefix: str, x: Tensor, k: int, dilations: Sequence[int]) -> Tensor:
     """ResBlock1.forward, modules.py:147-154: 3x [lrelu -> dilated conv -> lrelu -> conv -> +x]."""

@@ -315,6 +315,33 @@ int qvc_flow_reverse(const qvc_config* cfg, const void* blob_dev, float* z_fm, c
   return c.status;
 }
 
+int qvc_flow_forward(const qvc_config* cfg, const void* blob_dev, float* z_fm, const float* g, int32_t batch,
+                     int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!z_fm || !g) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.cond_table(g);
+  c.flow(z_fm, /*forward=*/true);
+  return c.status;
+}
+
+int qvc_enc_q(const qvc_config* cfg, const void* encq_blob_dev, const float* spec, const float* g, const float* noise,
+              float* z_fm, int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!spec || !g || !noise || !z_fm) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, encq_blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  const EncQPlan Q = build_encq_plan(*cfg);
+  if (Q.status != QVC_OK) return Q.status;
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
+  Ctx c{P, static_cast<const char*>(encq_blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  c.enc_q(Q, static_cast<const char*>(encq_blob_dev), spec, g, noise, z_fm);
+  return c.status;
+}
+
 int qvc_dec_trunk(const qvc_config* cfg, const void* blob_dev, const float* z_fm, const float* g, float* post_fm,
                   int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!z_fm || !g || !post_fm) return QVC_ERR_BAD_ARG;

@@ -936,8 +936,8 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
           if (q >= q0 && q < q0 + kWnOutFrames && q < a.T) {
             float* p = a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v;
             float4 zz = *reinterpret_cast<const float4*>(p);
-            zz.x -= qacc[m][n][0] + bq.x; zz.y -= qacc[m][n][1] + bq.y;
-            zz.z -= qacc[m][n][2] + bq.z; zz.w -= qacc[m][n][3] + bq.w;
+            zz.x += a.post_sign * (qacc[m][n][0] + bq.x); zz.y += a.post_sign * (qacc[m][n][1] + bq.y);
+            zz.z += a.post_sign * (qacc[m][n][2] + bq.z); zz.w += a.post_sign * (qacc[m][n][3] + bq.w);
             *reinterpret_cast<float4*>(p) = zz;
           }
         }

@@ -89,6 +89,7 @@ struct WnStackArgs {
   const void* w_pre = nullptr; const float* b_pre = nullptr; int32_t pre_cin = 0, pre_c0 = 0, pre_KS = 0;
   const void* w_post = nullptr; const float* b_post = nullptr; int32_t post_m = 0, post_c0 = 0, post_mf = 0;
   float* z = nullptr; int64_t z_bs = 0; int32_t z_ts = 0;
+  float post_sign = -1.f;   // -1: reverse flow, x1 - m (modules.py:217); +1: forward flow, m + x1
 };
 
 struct GemvArgs {

@@ -283,6 +283,44 @@ extern "C" int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors
   return pk.status;
 }
 
+// ---------------------------------------------------------------- enc_q blob (models.py:582: CondNormalWN with gin)
+extern "C" int64_t qvc_encq_blob_bytes(const qvc_config* cfg) {
+  if (!cfg) return QVC_ERR_BAD_ARG;
+  EncQPlan Q = build_encq_plan(*cfg);
+  return Q.status == QVC_OK ? Q.blob_bytes : (int64_t)Q.status;
+}
+
+extern "C" int qvc_encq_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors, int32_t n_tensors,
+                                     void* blob_host, int64_t blob_bytes) {
+  if (!cfg || !tensors || n_tensors <= 0 || !blob_host) return QVC_ERR_BAD_ARG;
+  EncQPlan Q = build_encq_plan(*cfg);
+  if (Q.status != QVC_OK) return Q.status;
+  if (blob_bytes < Q.blob_bytes) return QVC_ERR_SMALL_BUFFER;
+  std::memset(blob_host, 0, (size_t)Q.blob_bytes);
+  Packer pk{*cfg, {}, static_cast<char*>(blob_host)};
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!tensors[i].name || !tensors[i].data || tensors[i].ndim < 0 || tensors[i].ndim > 4) return QVC_ERR_BAD_ARG;
+    pk.tensors[tensors[i].name] = &tensors[i];
+  }
+  const int H = cfg->hidden_channels, gin = cfg->gin_channels, L = cfg->enc_layers;
+  pk.pack_conv1d(Q.pre, "enc_q.pre");
+  pk.pack_wn(Q.wn, "enc_q.enc");
+  pk.pack_conv1d(Q.proj, "enc_q.proj");
+  if (pk.status != QVC_OK) return pk.status;
+  // conditioning rows: cond_layer (weight-normed 1x1 on g, modules.py:54,84) + the in_layer biases (modules.py:91)
+  float* cond_w = reinterpret_cast<float*>(pk.blob + Q.cond_w_off);
+  float* cond_b = reinterpret_cast<float*>(pk.blob + Q.cond_b_off);
+  auto w = pk.weight("enc_q.enc.cond_layer", (int64_t)L * 2 * H, gin, 1);
+  auto b = pk.bias("enc_q.enc.cond_layer", (int64_t)L * 2 * H);
+  if (pk.status != QVC_OK) return pk.status;
+  std::memcpy(cond_w, w.data(), w.size() * 4);
+  for (int l = 0; l < L && pk.status == QVC_OK; ++l) {
+    auto ib = pk.bias("enc_q.enc.in_layers." + std::to_string(l), 2 * H);
+    for (int r = 0; r < 2 * H; ++r) cond_b[(size_t)l * 2 * H + r] = b[(size_t)l * 2 * H + r] + ib[(size_t)r];
+  }
+  return pk.status;
+}
+
 // ---------------------------------------------------------------- speaker encoder blob (models.py:507-518)
 extern "C" int64_t qvc_spk_blob_bytes(const qvc_config* cfg) {
   if (!cfg) return QVC_ERR_BAD_ARG;

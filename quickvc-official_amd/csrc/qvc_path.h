@@ -31,10 +31,11 @@ struct Path {
   template <typename U> U* wsp(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
   int dtype() const { return P.cfg.operand_dtype; }
 
-  ConvArgs args(const ConvDesc& d) const {
+  ConvArgs args(const ConvDesc& d, const char* wb = nullptr) const {
     ConvArgs a;
-    a.w = blob + d.w_off;
-    a.bias = d.b_off >= 0 ? reinterpret_cast<const float*>(blob + d.b_off) : nullptr;
+    if (!wb) wb = blob;
+    a.w = wb + d.w_off;
+    a.bias = d.b_off >= 0 ? reinterpret_cast<const float*>(wb + d.b_off) : nullptr;
     a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left;
     a.KS = d.KS(); a.nIt = d.nIt(); a.nchunk = d.nchunk; a.M = d.M;
     a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout;
@@ -61,7 +62,8 @@ struct Path {
 
   // ---- WN stack over xw (in place) accumulating into oacc (modules.py:69-114)
   // bb: conditioning rows for layer 0 (+ l*2H per layer), bb_bs: batch stride (0 = shared)
-  void wn(const WNPlan& wn, const float* bb, int64_t bb_bs) {
+  void wn(const WNPlan& wn, const float* bb, int64_t bb_bs, const char* wb = nullptr) {
+    if (!wb) wb = blob;
     const int H = P.cfg.hidden_channels;
     const int64_t bs = (int64_t)T * H;
     // Whole-stack kernel, in launches of `chunk` layers: fewer layers per launch = less halo to recompute
@@ -74,8 +76,8 @@ struct Path {
         a.x0 = wsp<float>(part % 2 == 0 ? W.xw : W.xw2);
         a.out = wsp<float>(W.oacc); a.bs = bs; a.T = T; a.H = H; a.HP = wn.in_conv[0].CinP;
         for (int l = 0; l < chunk; ++l) {
-          a.w_in[l] = blob + wn.in_conv[l0 + l].w_off; a.w_rs[l] = blob + wn.rs_conv[l0 + l].w_off;
-          a.b_rs[l] = reinterpret_cast<const float*>(blob + wn.rs_conv[l0 + l].b_off);
+          a.w_in[l] = wb + wn.in_conv[l0 + l].w_off; a.w_rs[l] = wb + wn.rs_conv[l0 + l].w_off;
+          a.b_rs[l] = reinterpret_cast<const float*>(wb + wn.rs_conv[l0 + l].b_off);
         }
         a.bbias = bb + (int64_t)l0 * 2 * H; a.bbias_bs = bb_bs;
         a.layers = chunk; a.taps = wn.in_conv[0].taps; a.KS = wn.in_conv[0].KS(); a.nIt1 = wn.in_conv[0].nIt();
@@ -95,8 +97,8 @@ struct Path {
       a.x_out = wsp<float>(l % 2 == 0 ? W.xw2 : W.xw);
       a.oacc = wsp<float>(W.oacc);
       a.bs = bs; a.T = T; a.H = H; a.HP = din.CinP;
-      a.w_in = blob + din.w_off; a.w_rs = blob + drs.w_off;
-      a.b_rs = reinterpret_cast<const float*>(blob + drs.b_off);
+      a.w_in = wb + din.w_off; a.w_rs = wb + drs.w_off;
+      a.b_rs = reinterpret_cast<const float*>(wb + drs.b_off);
       a.bbias = bb + (int64_t)l * 2 * H; a.bbias_bs = bb_bs;
       a.taps = din.taps; a.KS = din.KS(); a.nIt1 = din.nIt(); a.last = l == wn.layers - 1 ? 1 : 0;
       if (status == QVC_OK) status = be.wn(din, drs, a, B, dtype());
@@ -127,12 +129,48 @@ struct Path {
     status = be.sample(sa);
   }
 
-  // ---- flow, reverse (models.py:39-51, modules.py:199-224); z updated in place
-  void flow(float* z) {
+  // ---- enc_q (models.py:75-95 with cond = g, :582,617): spec, g, noise -> z
+  void enc_q(const EncQPlan& Q, const char* qblob, const float* spec, const float* g, const float* noise, float* z_out) {
+    const qvc_config& c = P.cfg;
+    const int H = c.hidden_channels, C = c.inter_channels;
+    if (status != QVC_OK) return;
+    GemvArgs ga{reinterpret_cast<const float*>(qblob + Q.cond_w_off), reinterpret_cast<const float*>(qblob + Q.cond_b_off),
+                g, wsp<float>(W.bb), Q.cond_rows, c.gin_channels, B};
+    status = be.gemv(ga);
+    {
+      ConvArgs a = args(Q.pre, qblob);
+      a.x = spec; a.x_kind = XK_F32_CM; a.x_bs = (int64_t)Q.spec_channels * T; a.x_ts = T; a.T_in = T;
+      a.Nq = T; a.T_out = T;
+      a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
+      conv(Q.pre, a);
+    }
+    wn(Q.wn, wsp<float>(W.bb), Q.cond_rows, qblob);
+    {
+      ConvArgs a = args(Q.proj, qblob);
+      a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
+      a.Nq = T; a.T_out = T;
+      a.y32 = wsp<float>(W.stats); a.y32_bs = (int64_t)T * 2 * C; a.y32_ts = 2 * C;
+      conv(Q.proj, a);
+    }
+    if (status != QVC_OK) return;
+    SampleArgs sa{wsp<float>(W.stats), noise, z_out, B, T, C};
+    status = be.sample(sa);
+  }
+
+  // ---- flow (models.py:39-51, modules.py:199-224); z updated in place.  reverse (the conversion path): the plan's
+  // steps in order, x1 <- x1 - m.  forward (the posterior direction, models.py:618): the same steps in the opposite
+  // order, x1 <- m + x1 -- every coupling layer sees the same channel flip in both directions (layer l is preceded by
+  // l flips going forward and by n-l going back, n even), so the flip-folded pre / post weights serve both.
+  void flow(float* z, bool forward = false) {
+    const float sign = forward ? 1.f : -1.f;
+    const size_t n = P.flow.size();
+    for (size_t s = 0; s < n; ++s) flow_step(P.flow[forward ? n - 1 - s : s], z, sign);
+  }
+  void flow_step(const FlowStepPlan& f, float* z, float sign) {
     const qvc_config& c = P.cfg;
     const int H = c.hidden_channels, C = c.inter_channels;
     const float* bb = wsp<float>(W.bb);
-    for (const FlowStepPlan& f : P.flow) {
+    {
       const ConvDesc& din = f.wn.in_conv[0];
       if (f.wn.layers == be.wn_stack_chunk(f.wn.layers) && wn_fuse_ok(din, f.pre, f.post, f.wn.layers) && be.use_wn_stack(B, T)) {
         // the whole coupling layer in ONE launch: pre 1x1 -> 4 WaveNet layers -> post 1x1 -> x1 -= m
@@ -148,10 +186,10 @@ struct Path {
         a.pre_cin = f.pre.Cin; a.pre_c0 = f.in_c0; a.pre_KS = f.pre.KS();
         a.w_post = blob + f.post.w_off; a.b_post = reinterpret_cast<const float*>(blob + f.post.b_off);
         a.post_m = f.post.M; a.post_c0 = f.out_c0; a.post_mf = f.post.MF;
-        a.z = z; a.z_bs = (int64_t)T * C; a.z_ts = C;
+        a.z = z; a.z_bs = (int64_t)T * C; a.z_ts = C; a.post_sign = sign;
         if (status == QVC_OK)
           status = be.wn_stack(din, f.wn.rs_conv[0], f.wn.rs_conv[f.wn.layers - 1], a, B, dtype(), &f.pre, &f.post);
-        continue;
+        return;
       }
       {
         ConvArgs a = args(f.pre);
@@ -161,11 +199,11 @@ struct Path {
         conv(f.pre, a);
       }
       wn(f.wn, bb + f.cond_row0, P.cond_rows);
-      {   // x1 <- x1 - post(h)   (modules.py:214-217)
+      {   // x1 <- x1 -/+ post(h)   (modules.py:214-217)
         ConvArgs a = args(f.post);
         a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
         a.Nq = T; a.T_out = T;
-        a.res = z; a.res_bs = (int64_t)T * C; a.res_ts = C; a.res_c0 = f.out_c0; a.res_sign = -1.f;
+        a.res = z; a.res_bs = (int64_t)T * C; a.res_ts = C; a.res_c0 = f.out_c0; a.res_sign = sign;
         a.y32 = z; a.y32_bs = (int64_t)T * C; a.y32_ts = C; a.y32_c0 = f.out_c0;
         conv(f.post, a);
       }

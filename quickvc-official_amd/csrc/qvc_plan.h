@@ -5,6 +5,7 @@
 // descriptor (shapes, padded shapes, byte offsets into the blob).  Nothing here is
 // stored in the blob itself, so packer and runtime can never disagree.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -345,7 +346,7 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off = align_up(off + n, 256); return o; };
   const int64_t BT = (int64_t)B * T;
-  W.bb = take((int64_t)B * P.cond_rows * 4);
+  W.bb = take((int64_t)B * std::max(P.cond_rows, c.enc_layers * 2 * c.hidden_channels) * 4);   // enc_q's table too
   W.xw = take(BT * c.hidden_channels * 4);
   W.xw2 = take(BT * c.hidden_channels * 4);
   W.oacc = take(BT * c.hidden_channels * 4);
@@ -365,6 +366,55 @@ inline Workspace carve_workspace(const Plan& P, int B, int T) {
   W.post = take((int64_t)B * (t + 1) * P.post_channels * 4);
   W.bytes = off;
   return W;
+}
+
+// ---------------------------------------------------------------- posterior encoder enc_q (models.py:582,617)
+// CondNormalWN(spec_channels -> inter, hidden, k5, 16 layers, gin): own blob, same kernels as enc_p; the
+// conditioning rows (cond_layer on g + in_layer biases) form its own GEMV table.
+struct EncQPlan {
+  int32_t status = QVC_OK;
+  int32_t spec_channels = 641;
+  ConvDesc pre, proj;
+  WNPlan wn;
+  int32_t cond_rows = 0;
+  int64_t cond_w_off = 0, cond_b_off = 0;
+  int64_t blob_bytes = 0;
+};
+
+inline EncQPlan build_encq_plan(const qvc_config& c) {
+  EncQPlan Q;
+  Q.status = validate(c);
+  if (Q.status != QVC_OK) return Q;
+  Q.spec_channels = c.spec_channels > 0 ? c.spec_channels : 641;
+  if (Q.spec_channels > 8192) { Q.status = QVC_ERR_BAD_CONFIG; return Q; }
+  const int H = c.hidden_channels, C = c.inter_channels, K = c.wn_kernel_size;
+  int64_t off = 0;
+  auto place = [&](ConvDesc& d, bool with_bias = true) {
+    d.w_off = off; off = align_up(off + d.w_bytes(), 256);
+    if (with_bias) { d.b_off = off; off = align_up(off + d.b_bytes(), 256); } else { d.b_off = -1; }
+  };
+  Q.pre = make_conv(H, Q.spec_channels, 1, 1);
+  if (Q.pre.WM < kWaves) {   // 641 input channels: a wave grid along the frames (WM < 4) would need a 4x wider LDS tile than fits
+    Q.pre.WM = kWaves; Q.pre.MF = std::min(4, ceil_div(ceil_div(H, 16), kWaves)); Q.pre.nchunk = ceil_div(H, kWaves * Q.pre.MF * 16);
+  }
+  place(Q.pre);
+  Q.wn.layers = c.enc_layers;
+  for (int i = 0; i < c.enc_layers; ++i) {
+    ConvDesc a = make_conv(2 * H, H, K, 1, /*gau=*/true);
+    wn_layout(a, 2);
+    place(a, /*with_bias=*/false);
+    Q.wn.in_conv.push_back(a);
+    ConvDesc r = make_conv(i < c.enc_layers - 1 ? 2 * H : H, H, 1, 1, /*gau=*/i < c.enc_layers - 1);
+    wn_layout(r, i < c.enc_layers - 1 ? 2 : 1);
+    place(r);
+    Q.wn.rs_conv.push_back(r);
+  }
+  Q.proj = make_conv(2 * C, H, 1, 1); place(Q.proj);
+  Q.cond_rows = c.enc_layers * 2 * H;
+  Q.cond_w_off = off; off = align_up(off + (int64_t)Q.cond_rows * c.gin_channels * 4, 256);
+  Q.cond_b_off = off; off = align_up(off + (int64_t)Q.cond_rows * 4, 256);
+  Q.blob_bytes = off;
+  return Q;
 }
 
 // ---------------------------------------------------------------- speaker encoder (models.py:507-546)

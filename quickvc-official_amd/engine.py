@@ -45,6 +45,9 @@ class QvcEngine:
         self._ws_key = None
         # speaker encoder: own blob, packed on first use from the same state dict
         self._spk_sd = {k: v for k, v in state_dict.items() if k.startswith("enc_spk.")}
+        # posterior encoder: own blob too, packed on first use
+        self._encq_sd = {k: v for k, v in state_dict.items() if k.startswith("enc_q.")}
+        self._encq_blob: Optional[torch.Tensor] = None
         self._spk_blob: Optional[torch.Tensor] = None
         self._spk_ws: Optional[torch.Tensor] = None
         n = model_config["gen_istft_hop_size"] * model_config["subbands"]
@@ -121,6 +124,37 @@ class QvcEngine:
                                         torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib, st, "qvc_speaker_embed")
         return g
+
+    def enc_q(self, spec: torch.Tensor, g: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """Posterior encoder, models.py:617: spec (B, spec_channels, T), g (B, gin), noise (B, inter, T) -> z [B][T][inter]."""
+        B, cs, T = spec.shape
+        mc = self.model_config
+        if cs != int(self.cfg.spec_channels) or g.shape != (B, mc["gin_channels"]) or tuple(noise.shape) != (B, mc["inter_channels"], T):
+            raise ValueError(f"bad input shapes: spec {tuple(spec.shape)}, g {tuple(g.shape)}, noise {tuple(noise.shape)}")
+        if self._encq_blob is None:
+            if not self._encq_sd:
+                raise L.QvcError("the state dict holds no enc_q.* weights")
+            host = L.pack_weights(self.lib, self.cfg, self._encq_sd, which="encq")
+            self._encq_blob = _aligned_empty(host.numel(), self.device)
+            self._encq_blob.copy_(host)
+        spec, g, noise = (self._f32(t, self.device) for t in (spec, g, noise))
+        z = torch.empty(B, T, mc["inter_channels"], dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T)
+        st = self.lib.qvc_enc_q(ctypes.byref(self.cfg), self._encq_blob.data_ptr(), spec.data_ptr(), g.data_ptr(), noise.data_ptr(),
+                                z.data_ptr(), B, T, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_enc_q")
+        return z
+
+    def flow_forward(self, z_fm: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        """ResidualCouplingBlock.forward(reverse=False), models.py:618: z [B][T][inter] -> z_p (a new tensor)."""
+        B, T, _ = z_fm.shape
+        z = self._f32(z_fm, self.device).clone()
+        g = self._f32(g, self.device)
+        ws = self.workspace(B, T)
+        st = self.lib.qvc_flow_forward(ctypes.byref(self.cfg), self.blob.data_ptr(), z.data_ptr(), g.data_ptr(), B, T,
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_flow_forward")
+        return z
 
     def infer_batch_timed(self, unit, g, noise, out=None, max_records: int = 512):
         """Same launches with per-launch HIP-event timing; returns (out, [dict(name, ms, flops, bytes)])."""

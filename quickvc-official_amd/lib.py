@@ -31,7 +31,7 @@ class QvcConfig(ctypes.Structure):
         ("resblock_kernel_sizes", ctypes.c_int32 * QVC_MAX_RESBLOCKS),
         ("resblock_dilations", (ctypes.c_int32 * 3) * QVC_MAX_RESBLOCKS),
         ("n_fft", ctypes.c_int32), ("hop", ctypes.c_int32), ("subbands", ctypes.c_int32), ("decoder", ctypes.c_int32),
-        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("n_mel_channels", ctypes.c_int32),
+        ("fir_taps", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("n_mel_channels", ctypes.c_int32), ("spec_channels", ctypes.c_int32),
     ]
 
 
@@ -96,6 +96,14 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_spk_workspace_bytes.argtypes = [cfgp, I, I]
         lib.qvc_speaker_embed.restype = ctypes.c_int
         lib.qvc_speaker_embed.argtypes = [cfgp, V, V, V, I, I, V, L, V]
+        lib.qvc_encq_blob_bytes.restype = L
+        lib.qvc_encq_blob_bytes.argtypes = [cfgp]
+        lib.qvc_encq_pack_weights.restype = ctypes.c_int
+        lib.qvc_encq_pack_weights.argtypes = [cfgp, P(QvcTensor), I, V, L]
+        lib.qvc_enc_q.restype = ctypes.c_int
+        lib.qvc_enc_q.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
+        lib.qvc_flow_forward.restype = ctypes.c_int
+        lib.qvc_flow_forward.argtypes = [cfgp, V, V, V, I, I, V, L, V]
         lib.qvc_mel_table_bytes.restype = L
         lib.qvc_mel_table_bytes.argtypes = [I, I]
         lib.qvc_mel_pack_tables.restype = ctypes.c_int
@@ -118,7 +126,7 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 3:
+        if lib.qvc_abi_version() != 4:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -161,6 +169,7 @@ def make_config(mc: dict) -> QvcConfig:
         raise QvcError(f"operand_dtype must be one of {sorted(DTYPES)}")
     c.operand_dtype = DTYPES[dt]
     c.n_mel_channels = int(mc.get("n_mel_channels", 80))
+    c.spec_channels = int(mc.get("spec_channels", 641))
     return c
 
 
@@ -170,7 +179,8 @@ def pack_weights(lib, cfg: QvcConfig, state_dict: Dict[str, torch.Tensor], which
     ``which``: "path" = enc_p / flow / dec (qvc_pack_weights), "spk" = the speaker encoder (qvc_spk_pack_weights).
     """
     bytes_fn, pack_fn = {"path": (lib.qvc_blob_bytes, lib.qvc_pack_weights),
-                         "spk": (lib.qvc_spk_blob_bytes, lib.qvc_spk_pack_weights)}[which]
+                         "spk": (lib.qvc_spk_blob_bytes, lib.qvc_spk_pack_weights),
+                         "encq": (lib.qvc_encq_blob_bytes, lib.qvc_encq_pack_weights)}[which]
     n = int(bytes_fn(ctypes.byref(cfg)))
     if n < 0:
         check(lib, n, bytes_fn.__name__)

@@ -245,7 +245,7 @@ class SynthesizerTrn(nn.Module):
             upsample_rates=list(upsample_rates), upsample_initial_channel=upsample_initial_channel,
             upsample_kernel_sizes=list(upsample_kernel_sizes), gen_istft_n_fft=gen_istft_n_fft,
             gen_istft_hop_size=gen_istft_hop_size, subbands=(int(subbands) if kind != "istft" else 1),
-            decoder=kind, operand_dtype=operand_dtype)
+            decoder=kind, operand_dtype=operand_dtype, spec_channels=int(spec_channels))
 
         self.enc_q = CondNormalWNParams(spec_channels, inter_channels, hidden_channels, 5, 16, gin_channels)
         self.enc_p = CondNormalWNParams(unit_channels, inter_channels, hidden_channels, 5, 16, 0)
@@ -297,6 +297,20 @@ class SynthesizerTrn(nn.Module):
         """
         g = self.speaker_embed(mel)                                               # models.py:635
         return self.infer_batch(unit, g, noise)
+
+    @torch.no_grad()
+    def posterior(self, spec: Tensor, g: Tensor, noise: Optional[Tensor] = None):
+        """The analysis half of ``forward`` (models.py:617-618): z ~ enc_q(spec | g), z_p = flow(z, g).
+
+        spec (B, spec_channels, T), g (B, gin) or (B, gin, 1), noise (B, inter, T) optional -> (z, z_p), both (B, inter, T).
+        """
+        eng = self.engine()
+        g = g.reshape(g.shape[0], -1)
+        if noise is None:
+            noise = torch.randn(spec.shape[0], self.model_config["inter_channels"], spec.shape[2], device=spec.device)
+        z = eng.enc_q(spec, g, noise)
+        z_p = eng.flow_forward(z, g)
+        return z.transpose(1, 2).contiguous(), z_p.transpose(1, 2).contiguous()
 
     @torch.no_grad()
     def speaker_embed(self, mel: Tensor) -> Tensor:

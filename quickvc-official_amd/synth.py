@@ -92,6 +92,20 @@ def make_synthetic_inputs(batch: int, frames: int, unit_channels: int, inter_cha
     return (torch.from_numpy(np.stack(units)), torch.from_numpy(np.stack(gs)), torch.from_numpy(np.stack(noises)))
 
 
+def make_synthetic_posterior_inputs(batch: int, frames: int, spec_channels: int, inter_channels: int, gin_channels: int,
+                                    seed0: int = 50):
+    """Inputs of the posterior direction (models.py:617-618): a linear-spectrogram-like spec = |N(0,1)| (B, spec, T)
+    (magnitudes are non-negative, mel_processing.py:56), g and noise as in ``make_synthetic_inputs``."""
+    specs, gs, noises = [], [], []
+    for b in range(batch):
+        rng = np.random.RandomState(seed0 + b)
+        specs.append(np.abs(rng.standard_normal(size=(spec_channels, frames))).astype(np.float32))
+        gv = np.abs(rng.standard_normal(size=(gin_channels,)))
+        gs.append((gv / np.sqrt((gv ** 2).sum())).astype(np.float32))
+        noises.append(rng.standard_normal(size=(inter_channels, frames)).astype(np.float32))
+    return (torch.from_numpy(np.stack(specs)), torch.from_numpy(np.stack(gs)), torch.from_numpy(np.stack(noises)))
+
+
 def make_synthetic_mel(frames: int, n_mel: int = 80, seed: int = 7) -> torch.Tensor:
     """A log-mel-like (1, n_mel, frames) tensor for the speaker-encoder path."""
     rng = np.random.RandomState(seed)

@@ -20,6 +20,10 @@ def load_emu():
     lib.qvc_emu_infer_batch.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, Lg]
     lib.qvc_emu_speaker_embed.restype = ctypes.c_int
     lib.qvc_emu_speaker_embed.argtypes = [P(L.QvcConfig), V, V, V, I, I, V, Lg]
+    lib.qvc_emu_enc_q.restype = ctypes.c_int
+    lib.qvc_emu_enc_q.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, Lg]
+    lib.qvc_emu_flow_forward.restype = ctypes.c_int
+    lib.qvc_emu_flow_forward.argtypes = [P(L.QvcConfig), V, V, V, I, I, V, Lg]
     lib.qvc_emu_tap_offset.restype = Lg
     lib.qvc_emu_tap_offset.argtypes = [P(L.QvcConfig), I, I, I]
     return lib
@@ -87,3 +91,28 @@ def emu_speaker_embed(model_config, sd, mel, dtype="f16"):
                                    ws.data_ptr(), n_ws)
     assert st == 0, hip.qvc_status_string(st)
     return g
+
+
+def emu_posterior(model_config, sd, spec, g, noise, dtype="f16"):
+    """Host replay of qvc_enc_q + qvc_flow_forward: returns (z, z_p) as (B, inter, T)."""
+    from quickvc_official_amd import lib as L
+    hip = L.load_library()
+    emu = load_emu()
+    cfg = L.make_config(dict(model_config, operand_dtype=dtype))
+    qblob = L.pack_weights(hip, cfg, {k: v for k, v in sd.items() if k.startswith("enc_q.")}, which="encq")
+    blob = L.pack_weights(hip, cfg, sd)
+    B, _, T = spec.shape
+    n_ws = int(hip.qvc_workspace_bytes(ctypes.byref(cfg), B, T))
+    raw = torch.zeros(n_ws + 256, dtype=torch.uint8)
+    shift = (-raw.data_ptr()) % 256
+    ws = raw[shift:shift + n_ws]
+    C = int(cfg.inter_channels)
+    spec, g, noise = spec.float().contiguous(), g.float().contiguous(), noise.float().contiguous()
+    z = torch.empty(B, T, C)
+    st = emu.qvc_emu_enc_q(ctypes.byref(cfg), qblob.data_ptr(), spec.data_ptr(), g.data_ptr(), noise.data_ptr(), z.data_ptr(),
+                           B, T, ws.data_ptr(), n_ws)
+    assert st == 0, hip.qvc_status_string(st)
+    zp = z.clone()
+    st = emu.qvc_emu_flow_forward(ctypes.byref(cfg), blob.data_ptr(), zp.data_ptr(), g.data_ptr(), B, T, ws.data_ptr(), n_ws)
+    assert st == 0, hip.qvc_status_string(st)
+    return z.transpose(1, 2).contiguous(), zp.transpose(1, 2).contiguous()

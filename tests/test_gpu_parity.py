@@ -439,3 +439,56 @@ def test_convert_cli_end_to_end(lib, dev, tmp_path):
         ref = net.infer_batch(unit, g.expand(2, -1))
         matches.append(np.array_equal(got_a, ref[order.index("a"), 0].cpu().numpy()))
     assert any(matches)
+
+
+# ------------------------------------------------------------------ posterior direction
+@pytest.mark.parametrize("name", ["mini_q", "odd_q"])
+def test_posterior_direction_vs_reference_golden(lib, dev, name):
+    """qvc_enc_q + qvc_flow_forward (models.py:617-618) vs what the reference produced (tests/golden/*_q.npz,
+    recorded by make_golden_q.py): z ~ enc_q(spec | g) and z_p = flow(z, g), f16 operands, >= 45 dB."""
+    import json
+    import os
+    import helpers
+    import quickvc_official_amd as q
+    from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_posterior_inputs
+    entry = json.load(open(os.path.join(helpers.GOLDEN, "manifest.json")))[name]
+    gold = dict(np.load(os.path.join(helpers.GOLDEN, entry["file"])))
+    cfg = entry["config"]
+    model = q.SynthesizerTrn(641, 32, **cfg)
+    sd = make_synthetic_state_dict(model, entry["weights_seed"])
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    spec, g, noise = make_synthetic_posterior_inputs(entry["batch"], entry["frames"], 641, cfg["inter_channels"], cfg["gin_channels"],
+                                                     seed0=entry["inputs_seed0"])
+    z, z_p = model.posterior(spec.to(dev), g.to(dev), noise.to(dev))
+    torch.cuda.synchronize()
+    assert z.shape == z_p.shape == (entry["batch"], cfg["inter_channels"], entry["frames"])
+    assert snr_db(gold["enc_q.z"], z.cpu().numpy()) >= 45.0
+    assert snr_db(gold["flow.z_p"], z_p.cpu().numpy()) >= 45.0
+
+
+def test_forward_flow_inverts_reverse_flow_at_benchmark_size(lib, dev):
+    """Size-independent property at B=32, T=250 (shipped config): flow(reverse) o flow(forward) = identity.  Both
+    directions compute m from the untouched half with the same kernels, so one coupling layer inverts to one fp32
+    add + subtract per element; across the four layers that 1e-7 perturbation of the next layer's input now and
+    then flips an f16 operand rounding, which bounds the round trip at ~70 dB (asserted >= 60).  The fallback path
+    (QVC_WN_CHUNK=-1: unfused pre/post) must agree with the fused one."""
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "f16")
+    _unit, g, noise = make_synthetic_inputs(32, 250, 256, 192, 256, seed0=700)
+    z = noise.transpose(1, 2).contiguous().to(dev)                    # any latent will do
+    z_p = eng.flow_forward(z, g)
+    back = eng.flow_reverse(z_p, g)
+    torch.cuda.synchronize()
+    assert snr_db(z.cpu(), z_p.cpu()) < 40.0                          # the flow did something
+    assert snr_db(z.cpu(), back.cpu()) >= 60.0
+    import os
+    os.environ["QVC_WN_CHUNK"] = "-1"
+    try:
+        z_p2 = eng.flow_forward(z[:3], g[:3])
+    finally:
+        del os.environ["QVC_WN_CHUNK"]
+    torch.cuda.synchronize()
+    assert snr_db(z_p[:3].cpu(), z_p2.cpu()) >= 100.0

@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "qvc.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
-    assert len(names) >= 22
+    assert len(names) >= 26
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 3
+    assert built.qvc_abi_version() == 4
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
 
 
@@ -111,6 +111,29 @@ def test_speaker_encoder_pack_and_host_emulation(built):
     cfg2 = L.make_config(dict(model.model_config)); cfg2.gin_channels = 320
     assert built.qvc_spk_blob_bytes(ctypes.byref(cfg2)) == -2
     assert built.qvc_spk_workspace_bytes(ctypes.byref(cfg), 0, 10) == -1
+
+
+@pytest.mark.parametrize("name", ["mini_q", "odd_q"])
+def test_posterior_direction_host_emulation(built, name):
+    """enc_q + forward flow (models.py:617-618): packed blobs + launch sequence replayed on the CPU vs the values the
+    reference produced (golden) and vs the oracle; the forward flow must invert the reverse flow."""
+    from emu import emu_posterior
+    from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_posterior_inputs
+    import quickvc_official_amd as q
+    entry = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))[name]
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", entry["file"])))
+    cfg = entry["config"]
+    model = q.SynthesizerTrn(641, 32, **cfg)
+    sd = make_synthetic_state_dict(model, entry["weights_seed"])
+    spec, g, noise = make_synthetic_posterior_inputs(entry["batch"], entry["frames"], 641, cfg["inter_channels"], cfg["gin_channels"],
+                                                     seed0=entry["inputs_seed0"])
+    otaps = {}
+    oracle.posterior_encode(sd, cfg, spec, g.unsqueeze(-1), noise, otaps)
+    for k in ("enc_q.m", "enc_q.logs", "enc_q.z", "flow.z_p"):                    # oracle pinned by the reference
+        assert np.abs(otaps[k].numpy() - gold[k]).max() <= 2e-5 * max(1.0, float(np.abs(gold[k]).max())), k
+    z, z_p = emu_posterior(model.model_config, sd, spec, g, noise)
+    assert snr_db(gold["enc_q.z"], z.numpy()) >= 50.0
+    assert snr_db(gold["flow.z_p"], z_p.numpy()) >= 50.0
 
 
 def test_mel_table_packer(built):
