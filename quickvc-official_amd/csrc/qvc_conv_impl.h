@@ -524,6 +524,21 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
       for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
     if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, 1, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
+    // All residual loads go out before the first store: x and y may alias as far as the compiler knows, so a
+    // load-add-store per fragment compiles to load, s_waitcnt vmcnt(0), store -- MF*NF serialised memory round
+    // trips at the tail of every workgroup (seen in the ISA; it was a third of the launch time).
+    quad rr[MF][NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int v = (wm * MF + m) * 16 + lq * 4;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = q0 + wn * (NF * 16) + n * 16 + lrow;
+        const bool ok = v < a.C && q < a.T && !QVC_ABL(3);
+        const size_t off = (size_t)b * a.bs + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0);
+        rr[m][n] = *reinterpret_cast<const quad*>(static_cast<const T*>(a.x) + off);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       const int v = (wm * MF + m) * 16 + lq * 4;
@@ -534,9 +549,9 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
         const int q = q0 + wn * (NF * 16) + n * 16 + lrow;
         if (q >= a.T) continue;
         const size_t off = (size_t)b * a.bs + (size_t)q * a.C + v;
-        const quad rr = *reinterpret_cast<const quad*>(static_cast<const T*>(a.x) + off);
-        float4 val = make_float4(acc[m][n][0] + bias.x + (float)rr[0], acc[m][n][1] + bias.y + (float)rr[1],
-                                 acc[m][n][2] + bias.z + (float)rr[2], acc[m][n][3] + bias.w + (float)rr[3]);
+        const quad r4 = rr[m][n];
+        float4 val = make_float4(acc[m][n][0] + bias.x + (float)r4[0], acc[m][n][1] + bias.y + (float)r4[1],
+                                 acc[m][n][2] + bias.z + (float)r4[2], acc[m][n][3] + bias.w + (float)r4[3]);
         quad h;
         h[0] = O::cvt(val.x); h[1] = O::cvt(val.y); h[2] = O::cvt(val.z); h[3] = O::cvt(val.w);
         *reinterpret_cast<quad*>(static_cast<T*>(a.y) + off) = h;
