@@ -53,23 +53,34 @@ int launch_gemv(const GemvArgs& a, void* stream) {
 }
 
 // ------------------------------------------------------------------ sampling
+// z[b][t][c] = mu + noise[b][c][t] * exp(logs): the noise arrives in the reference's (B, C, T) layout, everything
+// else is frame-major, so a 32 x 32 tile goes through LDS -- both the read (along t) and the write (along c) are
+// coalesced (reading the noise with c fastest cost a 64-byte sector per 4 bytes).
 __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs a) {
-  const size_t n = (size_t)a.batch * a.frames * a.C;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const int c = (int)(i % a.C);
-    const size_t bt = i / a.C;
-    const int t = (int)(bt % a.frames);
-    const size_t b = bt / a.frames;
-    const float mu = a.stats[bt * 2 * a.C + c], logs = a.stats[bt * 2 * a.C + a.C + c];
-    const float eps = a.noise[(b * a.C + c) * a.frames + t];
-    a.z[i] = mu + eps * expf(logs);
+  __shared__ float s_n[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+#pragma unroll
+  for (int cc = ty; cc < 32; cc += 8) {
+    const int c = c0 + cc, t = t0 + tx;
+    s_n[cc][tx] = (c < a.C && t < a.frames) ? a.noise[((size_t)b * a.C + c) * a.frames + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tt = ty; tt < 32; tt += 8) {
+    const int t = t0 + tt, c = c0 + tx;
+    if (t < a.frames && c < a.C) {
+      const size_t bt = (size_t)b * a.frames + t;
+      const float mu = a.stats[bt * 2 * a.C + c], logs = a.stats[bt * 2 * a.C + a.C + c];
+      a.z[bt * a.C + c] = mu + s_n[tx][tt] * expf(logs);
+    }
   }
 }
 
 int launch_sample(const SampleArgs& a, void* stream) {
-  const size_t n = (size_t)a.batch * a.frames * a.C;
-  const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  if (a.batch <= 0 || a.frames <= 0 || a.C <= 0) return QVC_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)ceil_div(a.frames, 32), (unsigned)ceil_div(a.C, 32), (unsigned)a.batch), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
@@ -78,7 +89,8 @@ int launch_sample(const SampleArgs& a, void* stream) {
 //   band signal   y_k[n], n in [0, 4(F-1)):  y = (sum_t w[m] x_t[m]) / (sum_t w[m]^2), m = n + 8 - 4t
 //   output        out[o], o in [0, 16(F-1)): out[o] = sum_k sum_n fir[k][4n - o + 31] * y_k[n]
 // One block = kOT consecutive output samples = kOT/4 band samples (+-7/8 halo) = kOT/16 frames (+-3/4).
-constexpr int kOT = 1024;                  // output samples per block
+constexpr int kOT = 912;                   // output samples per block: 57 + 7 = 64 frames x 4 bands = exactly one
+                                           // (frame, band) item per thread in the DFT phase (1024 needed two rounds)
 constexpr int kNY = kOT / 4 + 15;          // band samples needed: [a0-7, a0+kOT/4+7]
 constexpr int kNFR = kOT / 16 + 7;         // frames needed: [f0-3, f0+kOT/16+3]
 constexpr int kBands = 4, kBins = 9, kPostC = kBands * 2 * kBins, kTaps = 63;
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   __syncthreads();
 
   // ---- polyphase synthesis FIR: thread -> 4 consecutive outputs o = o0 + 4*tid + r
-  {
+  if (tid < kOT / 4) {
     const int ia = tid + 7;                                  // s_y index of band sample a = a0 + tid
     float out[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
