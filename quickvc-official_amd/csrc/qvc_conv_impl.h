@@ -945,12 +945,20 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         const int v = (wm * PM + m) * 16 + lq * 4;
         if (v >= a.post_m) continue;
         const float4 bq = *reinterpret_cast<const float4*>(a.b_post + v);
+        float4 zin[ON];                      // all loads of the read-modify-write before its first store
+#pragma unroll
+        for (int n = 0; n < ON; ++n) {
+          const int q = w0 + (OLO + n) * 16 + lrow;
+          zin[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q >= q0 && q < q0 + kWnOutFrames && q < a.T)
+            zin[n] = *reinterpret_cast<const float4*>(a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v);
+        }
 #pragma unroll
         for (int n = 0; n < ON; ++n) {
           const int q = w0 + (OLO + n) * 16 + lrow;
           if (q >= q0 && q < q0 + kWnOutFrames && q < a.T) {
             float* p = a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v;
-            float4 zz = *reinterpret_cast<const float4*>(p);
+            float4 zz = zin[n];
             zz.x += a.post_sign * (qacc[m][n][0] + bq.x); zz.y += a.post_sign * (qacc[m][n][1] + bq.y);
             zz.z += a.post_sign * (qacc[m][n][2] + bq.z); zz.w += a.post_sign * (qacc[m][n][3] + bq.w);
             *reinterpret_cast<float4*>(p) = zz;

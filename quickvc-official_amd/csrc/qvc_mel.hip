@@ -74,13 +74,23 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const StftArgs a) {
   // stage padded samples [f0*hop, f0*hop + (kMelFrames-1)*hop + n_fft), reflect padding as F.pad(mode='reflect')
   const int piece = (kMelFrames - 1) * a.hop + a.n_fft;
   const float* wv = a.wave + (size_t)u * a.samples;
-  for (int i = tid; i < piece; i += 256) {
-    int s = f0 * a.hop + i - a.pad;                   // index into the unpadded waveform
-    if (s < 0) s = -s;
-    if (s >= a.samples) s = 2 * (a.samples - 1) - s;
-    float v = 0.f;
-    if (s >= 0 && s < a.samples) v = wv[s];            // frames past the end of the utterance read zeros
-    s_x[mel_lds_idx(i, a.hop)] = v;
+  constexpr int kStageU = 8;                          // loads in flight per thread (one per loop trip = serialised round trips)
+  for (int base = tid; base < piece; base += 256 * kStageU) {
+    float v[kStageU];
+#pragma unroll
+    for (int j = 0; j < kStageU; ++j) {
+      const int i = base + j * 256;
+      int s = f0 * a.hop + i - a.pad;                 // index into the unpadded waveform
+      if (s < 0) s = -s;
+      if (s >= a.samples) s = 2 * (a.samples - 1) - s;
+      v[j] = 0.f;
+      if (i < piece && s >= 0 && s < a.samples) v[j] = wv[s];   // frames past the end of the utterance read zeros
+    }
+#pragma unroll
+    for (int j = 0; j < kStageU; ++j) {
+      const int i = base + j * 256;
+      if (i < piece) s_x[mel_lds_idx(i, a.hop)] = v[j];
+    }
   }
   __syncthreads();
 

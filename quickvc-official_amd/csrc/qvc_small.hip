@@ -16,29 +16,36 @@ namespace qvc {
 // the g vectors are staged into LDS once per workgroup ([k][b], so the 32 utterances of one k sit in
 // 32 different banks), each thread owns one (row, utterance) pair and walks k with the weight row read
 // as wave-wide broadcasts.  ~0.1 GFLOP in total: latency-sized, it only has to stay out of the way.
-constexpr int kGR = 8, kGB = 32;
+constexpr int kGR = 8, kGB = 32, kGS = kGB + 1;
 __global__ __launch_bounds__(256) void cond_gemv_kernel(const GemvArgs a) {
-  extern __shared__ float s_g[];                        // [gin][kGB]
+  extern __shared__ float s_g[];                        // [gin][kGS]
   const int tid = threadIdx.x;
   const int r = tid >> 5, bl = tid & 31;
   const int row = blockIdx.x * kGR + r;
   for (int b0 = 0; b0 < a.batch; b0 += kGB) {
     __syncthreads();
-    for (int i = tid; i < a.gin * kGB; i += 256) {
-      const int k = i >> 5, b = i & 31;
-      s_g[i] = (b0 + b < a.batch) ? a.g[(size_t)(b0 + b) * a.gin + k] : 0.f;
+    // coalesced along k, all 32 loads of a thread in flight at once (one element per loop trip cost 32 serialised
+    // round trips -- most of this kernel's 27 us); [k][kGS] keeps the transposing store conflict-free
+    for (int k = tid; k < a.gin; k += 256) {
+      float v[kGB];
+#pragma unroll
+      for (int bb = 0; bb < kGB; ++bb) v[bb] = (b0 + bb < a.batch) ? a.g[(size_t)(b0 + bb) * a.gin + k] : 0.f;
+#pragma unroll
+      for (int bb = 0; bb < kGB; ++bb) s_g[k * kGS + bb] = v[bb];
     }
     __syncthreads();
     if (row < a.rows && b0 + bl < a.batch) {
       const float* wr = a.w + (size_t)row * a.gin;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int k = 0;
+      // 16 weight loads in flight per thread: walked one float4 at a time the loop pays a cache round trip per step
+#pragma unroll 16
       for (; k + 4 <= a.gin; k += 4) {
         const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
-        s0 = fmaf(w4.x, s_g[(k + 0) * kGB + bl], s0); s1 = fmaf(w4.y, s_g[(k + 1) * kGB + bl], s1);
-        s2 = fmaf(w4.z, s_g[(k + 2) * kGB + bl], s2); s3 = fmaf(w4.w, s_g[(k + 3) * kGB + bl], s3);
+        s0 = fmaf(w4.x, s_g[(k + 0) * kGS + bl], s0); s1 = fmaf(w4.y, s_g[(k + 1) * kGS + bl], s1);
+        s2 = fmaf(w4.z, s_g[(k + 2) * kGS + bl], s2); s3 = fmaf(w4.w, s_g[(k + 3) * kGS + bl], s3);
       }
-      for (; k < a.gin; ++k) s0 = fmaf(wr[k], s_g[k * kGB + bl], s0);
+      for (; k < a.gin; ++k) s0 = fmaf(wr[k], s_g[k * kGS + bl], s0);
       a.out[(size_t)(b0 + bl) * a.rows + row] = (s0 + s1) + (s2 + s3) + a.bias[row];
     }
   }
@@ -46,8 +53,14 @@ __global__ __launch_bounds__(256) void cond_gemv_kernel(const GemvArgs a) {
 
 int launch_gemv(const GemvArgs& a, void* stream) {
   if (a.rows <= 0) return QVC_OK;
-  if (a.gin % 4 || (size_t)a.gin * kGB * 4 > 64 * 1024) return QVC_ERR_BAD_CONFIG;
-  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, kGR)), dim3(256), (size_t)a.gin * kGB * 4,
+  if (a.gin % 4 || (size_t)a.gin * kGS * 4 > 160 * 1024) return QVC_ERR_BAD_CONFIG;
+  static bool attr_done = false;                             // one-time opt-in for > 64 KiB dynamic LDS (gin > 496)
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cond_gemv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return QVC_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, kGR)), dim3(256), (size_t)a.gin * kGS * 4,
                      static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
@@ -110,12 +123,22 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   const float* pb = a.post + (size_t)b * a.F * kPostC;
 
   // ---- stage frames [f_lo, f_lo+kNFR) x 72 channels (contiguous in memory), float4 coalesced
-  for (int i = tid; i < kNFR * (kPostC / 4); i += 256) {
-    const int fr = i / (kPostC / 4), c4 = i - fr * (kPostC / 4);
-    const int t = f_lo + fr;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t >= 0 && t < a.F) v = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
-    *reinterpret_cast<float4*>(&s_post[fr * kPostC + c4 * 4]) = v;
+  {   // all of a thread's loads go out before its first LDS store (one per loop trip = serialised round trips)
+    constexpr int kChunks = kNFR * (kPostC / 4), kPer = (kChunks + 255) / 256;
+    float4 v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int i = tid + u * 256;
+      const int fr = i / (kPostC / 4), c4 = i - fr * (kPostC / 4);
+      const int t = f_lo + fr;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < kChunks && t >= 0 && t < a.F) v[u] = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int i = tid + u * 256;
+      if (i < kChunks) *reinterpret_cast<float4*>(&s_post[i * 4]) = v[u];
+    }
   }
   if (tid < kBands * 64) {
     const int k = tid >> 6, j = tid & 63;
