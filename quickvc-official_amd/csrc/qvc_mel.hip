@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void mel_log_kernel(const MelArgs a) {
     const float* sp = a.spec + ((size_t)u * a.frames + f) * a.binsP;
     const float* bs = a.basis + (size_t)m * a.bins;
     float s = 0.f;
+#pragma unroll 8
     for (int b = lo; b < hi; ++b) s = fmaf(bs[b], sp[b], s);
     a.mel[i] = logf(fmaxf(s, 1e-5f));
   }

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void spk_embed_kernel(const SpkEmbedArgs a) {
       if (row < H) {
         const float* wr = lw + (size_t)row * H;
         float s = lb[row];
+#pragma unroll 16                                     // 16 weight loads in flight (one per trip = a cache round trip each)
         for (int k = 0; k < H; k += 4) {
           const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
           s = fmaf(w4.x, s_h[k], s); s = fmaf(w4.y, s_h[k + 1], s); s = fmaf(w4.z, s_h[k + 2], s); s = fmaf(w4.w, s_h[k + 3], s);
