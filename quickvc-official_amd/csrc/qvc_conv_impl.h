@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "qvc_kernels.h"
+#include "qvc_launch_util.h"
 
 namespace qvc {
 
@@ -1022,12 +1023,8 @@ inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* n
 template <typename T, int MF, int NF, int WM, int EPI>
 inline int launch_one(const ConvArgs& a, int batch, size_t lds, hipStream_t stream) {
   auto kern = conv_mfma_kernel<T, MF, NF, WM, EPI>;
-  static bool attr_done = false;                             // one-time opt-in for > 64 KiB dynamic LDS
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return QVC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
+  if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   constexpr int NT = (kWaves / WM) * NF * 16;
   dim3 grid((unsigned)ceil_div(a.Nq, NT), (unsigned)batch, (unsigned)a.nchunk);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
@@ -1104,12 +1101,8 @@ inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
 template <typename T, int MF, int NF, int WM, int NWV>
 inline int launch_pair_one(const PairArgs& a, int batch, size_t lds, hipStream_t stream) {
   auto kern = rbpair_kernel<T, MF, NF, WM, NWV>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return QVC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
+  if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   constexpr int NT = (NWV / WM) * NF * 16;
   hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, NT), (unsigned)batch), dim3(NWV * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
@@ -1186,12 +1179,8 @@ template <typename T, int NF, int PM, int WV>
 inline int launch_wn_stack_pm(const WnStackArgs& a, int waves, int batch, hipStream_t stream) {
   auto kern = wn_stack_kernel<T, NF, PM, WV>;
   const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return QVC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
+  if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, kWnOutFrames), (unsigned)batch), dim3((unsigned)waves * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }

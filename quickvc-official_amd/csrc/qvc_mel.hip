@@ -11,6 +11,7 @@
 // The mel stage exploits the filters' sparsity (each triangle spans a few dozen bins): one thread per
 // (utterance, frame, filter) walks its own bin range.
 #include <hip/hip_runtime.h>
+#include "qvc_launch_util.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -258,12 +259,8 @@ extern "C" int qvc_wave_to_mel(const void* table_dev, int32_t n_fft, int32_t hop
   const int piece = (kMelFrames - 1) * hop + n_fft;
   const size_t lds = (size_t)(piece + (piece / hop + 1) * kMelPadEvery) * 4;
   if (lds > 160 * 1024) return QVC_ERR_BAD_CONFIG;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return QVC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
+  if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(stft_mag_kernel))) return QVC_ERR_LAUNCH;
   hipLaunchKernelGGL(stft_mag_kernel, dim3((unsigned)ceil_div(frames, kMelFrames), (unsigned)utterances, (unsigned)t.nchunk), dim3(256), lds, s, sa);
   if (hipGetLastError() != hipSuccess) return QVC_ERR_LAUNCH;
   MelArgs ma;

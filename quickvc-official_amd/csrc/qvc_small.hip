@@ -7,6 +7,7 @@
 //                          zero-stuffed intermediate, each post-conv frame read once (+halo).
 //   * fm_to_cm_kernel    : frame-major -> (B,C,T) for the unit-test conv entry point.
 #include <hip/hip_runtime.h>
+#include "qvc_launch_util.h"
 #include "qvc_kernels.h"
 
 namespace qvc {
@@ -54,12 +55,8 @@ __global__ __launch_bounds__(256) void cond_gemv_kernel(const GemvArgs a) {
 int launch_gemv(const GemvArgs& a, void* stream) {
   if (a.rows <= 0) return QVC_OK;
   if (a.gin % 4 || (size_t)a.gin * kGS * 4 > 160 * 1024) return QVC_ERR_BAD_CONFIG;
-  static bool attr_done = false;                             // one-time opt-in for > 64 KiB dynamic LDS (gin > 496)
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cond_gemv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return QVC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
+  if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(cond_gemv_kernel))) return QVC_ERR_LAUNCH;
   hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, kGR)), dim3(256), (size_t)a.gin * kGS * 4,
                      static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;

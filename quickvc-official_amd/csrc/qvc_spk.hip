@@ -16,6 +16,7 @@
 // run across the step boundary (the stream is periodic and data-independent).  That stream -- not the MFMA
 // pipe (64 MFMAs per wave per step) -- sets the step time.
 #include <hip/hip_runtime.h>
+#include "qvc_launch_util.h"
 #include "qvc_conv_impl.h"
 #include "qvc_path.h"
 
@@ -222,12 +223,8 @@ static int launch_lstm_last(const LstmArgs& a, hipStream_t stream) {
   constexpr int HPs = KS * 32 + 8;
   const size_t lds = (size_t)2 * kSpkCols * HPs * sizeof(T) + (size_t)KS * KLDS * 8 * 1024;
   auto kern = lstm_layer_kernel<T, KS, KREG, KLDS, RING, LAST>;
-  static bool attr_done = false;                             // one-time opt-in for > 64 KiB dynamic LDS
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return QVC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
+  if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.P, kSpkCols)), dim3((unsigned)KS * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
