@@ -136,6 +136,26 @@ def test_posterior_direction_host_emulation(built, name):
     assert snr_db(gold["flow.z_p"], z_p.numpy()) >= 50.0
 
 
+def test_encq_pack_error_codes(built):
+    """qvc_encq_pack_weights: tolerant of unrelated keys, loud on a missing / mis-shaped enc_q tensor."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd import lib as L
+    from quickvc_official_amd.synth import make_synthetic_state_dict
+    model = q.SynthesizerTrn(641, 32, **q.MINI_MODEL_CONFIG)
+    sd = make_synthetic_state_dict(model, 3)
+    cfg = L.make_config(model.model_config)
+    assert int(cfg.spec_channels) == 641
+    only_q = {k: v for k, v in sd.items() if k.startswith("enc_q.")}
+    blob = L.pack_weights(built, cfg, only_q, which="encq")
+    assert blob.numel() == built.qvc_encq_blob_bytes(ctypes.byref(cfg))
+    assert torch.equal(L.pack_weights(built, cfg, sd, which="encq"), blob)          # extra keys are ignored
+    with pytest.raises(L.QvcError, match="missing"):
+        L.pack_weights(built, cfg, {k: v for k, v in only_q.items() if k != "enc_q.enc.cond_layer.weight_v"}, which="encq")
+    bad = dict(only_q); bad["enc_q.pre.weight"] = only_q["enc_q.pre.weight"][:, :-1]
+    with pytest.raises(L.QvcError, match="shape"):
+        L.pack_weights(built, cfg, bad, which="encq")
+
+
 def test_mel_table_packer(built):
     """qvc_mel_pack_tables (host code): the windowed DFT table, unpacked with the kernel's index math, equals
     hann[k] * cos / -sin(2 pi bin k / n_fft); filter ranges cover exactly the non-zero weights; error codes."""
