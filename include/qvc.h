@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 4
+#define QVC_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -174,6 +174,14 @@ int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev,
 int qvc_enc_p(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* noise,
               float* z_p_fm, int32_t batch, int32_t frames,
               void* workspace, int64_t workspace_bytes, void* stream);
+/* WN.forward, modules.py:69-114: one of the path's WaveNet stacks on its own.
+ *   which = 0: enc_p.enc (enc_layers layers, g = NULL: no conditioning, modules.py:98)
+ *   which = 1 + i: flow.flows[2*i].enc (flow_layers layers, conditioned on g through cond_layer, modules.py:83-96)
+ *   x_fm [B][T][hidden] fp32 (the stack's input, i.e. the output of the `pre` 1x1)  ->  out_fm [B][T][hidden] fp32
+ *   (the sum of the skip paths = WN's return value).  x_fm and out_fm must not overlap. */
+int qvc_wn_stack(const qvc_config* cfg, const void* blob_dev, int32_t which, const float* x_fm, const float* g,
+                 float* out_fm, int32_t batch, int32_t frames,
+                 void* workspace, int64_t workspace_bytes, void* stream);
 /* ResidualCouplingBlock.forward(reverse=True), models.py:39-51: in place on z. */
 int qvc_flow_reverse(const qvc_config* cfg, const void* blob_dev, float* z_fm, const float* g,
                      int32_t batch, int32_t frames,

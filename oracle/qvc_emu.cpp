@@ -60,6 +60,11 @@ float round_op(float f, int dtype) {
 float lrelu(float x, float s) { return x > 0.f ? x : x * s; }
 
 struct EmuBackend {
+  // accumulator row of packed position (chunk, wave, mf, i): the physical position, except for lane-packed
+  // layouts (ConvDesc::lp), whose standard epilogue addresses rows by channel
+  static int row_of(const ConvDesc& d, int chunk, int wave, int mf, int i) {
+    return d.lp ? conv_row(d, chunk, wave, mf, i) : ((chunk * d.WM + wave) * d.MF + mf) * 16 + i;
+  }
   void fork(int) {} void branch(int) {} void branch_done(int) {} void wait_branch_done(int) {} void join(int) {}
   // ---- conv: dense weights are recovered from the fragment stream with the kernel's index math
   int conv(const ConvDesc& d, const ConvArgs& a, int B, int epi, int dtype) {
@@ -74,7 +79,8 @@ struct EmuBackend {
               for (int j = 0; j < 8; ++j) {
                 const size_t frag = ((size_t)(chunk * d.WM + wave) * nIt + it) * d.MF + mf;
                 const uint16_t h = src[(frag * 64 + lane) * 8 + j];
-                const int prow = ((chunk * d.WM + wave) * d.MF + mf) * 16 + (lane & 15);
+                const int prow = row_of(d, chunk, wave, mf, lane & 15);
+                if (prow < 0) continue;
                 const int k = (lane >> 4) * 8 + j;
                 W[((size_t)prow * nIt + it) * kKStep + k] = dtype == QVC_F16 ? from_f16(h) : from_bf16(h);
               }
@@ -115,7 +121,8 @@ struct EmuBackend {
         for (int wave = 0; wave < d.WM; ++wave)
           for (int mf = 0; mf < d.MF; ++mf)
             for (int i = 0; i < 16; ++i) {
-              const int prow = ((chunk * d.WM + wave) * d.MF + mf) * 16 + i;
+              const int prow = row_of(d, chunk, wave, mf, i);
+              if (prow < 0) continue;
               for (int q = 0; q < a.Nq; ++q) {
                 double acc = 0.0;
                 for (int it = 0; it < nIt; ++it) {
@@ -287,6 +294,10 @@ struct EmuBackend {
     a2.Nq = p.T; a2.T_out = p.T; a2.res16 = p.x; a2.res_bs = p.bs; a2.res_ts = p.C;
     a2.y16 = p.y; a2.y16_bs = p.bs; a2.y16_ts = p.C; a2.slope_out = 1.f;
     conv(d2, a2, B, EPI_STD, dtype);
+    return QVC_OK;
+  }
+  int pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int B, int dtype) {
+    for (int i = 0; i < a.n; ++i) pair(d1[i], d2[i], a.p[i], B, dtype);
     return QVC_OK;
   }
   int gemv(const GemvArgs& a) {

@@ -70,6 +70,7 @@ struct HipBackend {
   hipStream_t stream0 = nullptr;
   int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) { return launch_conv(d, a, batch, epi, dtype, stream); }
   int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& a, int batch, int dtype) { return launch_pair(d1, d2, a, batch, dtype, stream); }
+  int pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype) { return launch_pair3(d1, d2, a, batch, dtype, stream); }
   int wn(const ConvDesc& din, const ConvDesc&, const WnArgs& a, int batch, int dtype) { return launch_wn(din, a, batch, dtype, stream); }
   // the stack kernel recomputes halo frames but a layer is bound by its weight stream, not by MFMA work: measured
   // no slower than one launch per layer at any batch (16.4 vs 17.9 us per layer at batch 1)
@@ -128,6 +129,22 @@ struct TimedBackend {
     std::snprintf(name, sizeof(name), "rbpair<%s,MF%d,NF%d,WM%d>", dtype == QVC_F16 ? "f16" : "bf16", d1.MF, nf, d1.WM);
     const double outs = (double)batch * a.T * a.C;
     note(name, 2.0 * 2.0 * outs * a.C * a.k, outs * 2 * 3 + (double)d1.w_bytes() + (double)d2.w_bytes());
+    return st;
+  }
+  int pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype) {
+    if (ev.empty()) mark();
+    int nf = 0;
+    int st = launch_pair3(d1, d2, a, batch, dtype, stream, &nf);
+    mark();
+    char name[48];
+    std::snprintf(name, sizeof(name), "rbpair%d<%s,MF%d,NF%d,WM%d>", a.n, dtype == QVC_F16 ? "f16" : "bf16", d1[0].MF, nf, d1[0].WM);
+    double fl = 0, by = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const double outs = (double)batch * a.p[i].T * a.p[i].C;
+      fl += 2.0 * 2.0 * outs * a.p[i].C * a.p[i].k;
+      by += outs * 2 * 3 + (double)d1[i].w_bytes() + (double)d2[i].w_bytes();
+    }
+    note(name, fl, by);
     return st;
   }
   int wn(const ConvDesc& din, const ConvDesc& drs, const WnArgs& a, int batch, int dtype) {
@@ -300,6 +317,31 @@ int qvc_enc_p(const qvc_config* cfg, const void* blob_dev, const float* unit, co
   Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
   c.enc_p(unit, noise, z_p_fm);
   return c.status;
+}
+
+int qvc_wn_stack(const qvc_config* cfg, const void* blob_dev, int32_t which, const float* x_fm, const float* g,
+                 float* out_fm, int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x_fm || !out_fm || which < 0 || (which > 0 && !g)) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  if (which > cfg->n_flows) return QVC_ERR_BAD_ARG;
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, frames, be};
+  const size_t bytes = (size_t)batch * frames * cfg->hidden_channels * 4;
+  if (hipMemcpyAsync(c.wsp<float>(W.xw), x_fm, bytes, hipMemcpyDeviceToDevice, be.stream) != hipSuccess) return QVC_ERR_LAUNCH;
+  if (which == 0) {
+    c.wn(P.enc_wn, reinterpret_cast<const float*>(static_cast<const char*>(blob_dev) + P.enc_wn.inbias_off), 0);
+  } else {
+    const FlowStepPlan* f = nullptr;
+    for (const FlowStepPlan& s : P.flow) if (s.layer == which - 1) f = &s;
+    if (!f) return QVC_ERR_BAD_ARG;
+    c.cond_table(g);
+    c.wn(f->wn, c.wsp<float>(W.bb) + f->cond_row0, P.cond_rows);
+  }
+  if (c.status != QVC_OK) return c.status;
+  if (hipMemcpyAsync(out_fm, c.wsp<float>(W.oacc), bytes, hipMemcpyDeviceToDevice, be.stream) != hipSuccess) return QVC_ERR_LAUNCH;
+  return QVC_OK;
 }
 
 int qvc_flow_reverse(const qvc_config* cfg, const void* blob_dev, float* z_fm, const float* g, int32_t batch,

@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "qvc_kernels.h"
 #include "qvc_launch_util.h"
 
@@ -78,6 +79,16 @@ __device__ __forceinline__ typename Op<T>::frag lrelu8(typename Op<T>::frag v, f
     r[i] = (T)(f > 0.f ? f : f * slope);     // exact in fp32, one rounding back to T
   }
   return r;
+}
+
+// f16: max(x, slope*x) with the product formed in fp32 (v_fma_mix, exact as above) and a packed max: 12 VALU
+// instructions per 16-byte chunk instead of ~45 for the compare / select form.
+template <>
+__device__ __forceinline__ f16x8 lrelu8<_Float16>(f16x8 v, float slope) {
+  f16x8 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = (_Float16)((float)v[i] * slope);
+  return __builtin_elementwise_max(v, s);
 }
 
 // A fragments are prefetched PF k-steps ahead through a register ring of PF+1 slots.  Bytes in flight per
@@ -175,6 +186,67 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
   typename Op<T>::frag ar[kPF + 1][MF];
   gemm_prime<T, MF, kPF>(ar, ap, nIt);
   gemm_loop_primed<T, MF, NF, kPF>(acc, ar, ap, nIt, KS, dil, tile, rowbytes, sm, colrow, lq);
+}
+
+// The K loop for ONE WAVE PER SIMD (persistent pair kernel).  With a partner wave on the SIMD the loop above is
+// fine: while one wave issues its loads the other's MFMAs keep the pipe busy.  Alone, the ~45 load / address
+// instructions of a k-step would sit between two MFMA clusters with the matrix pipe idle.  Here every step is one
+// straight-line block -- loads are unconditional (the prefetch index and the tap wrap around instead of being
+// skipped at the tail, so they stay in bounds) -- and sched_group_barrier lays it out as
+//   MF MFMAs, the MF weight loads, then (one LDS read, MF MFMAs) ...
+// so each 16-cycle MFMA covers the issue of the next load.  RB = compile-time row pitch in bytes (0: runtime), which
+// turns the NF fragment addresses of a step into immediate offsets of one base register.
+template <typename T, int MF, int NF, int kPF, int RB>
+__device__ __forceinline__ void gemm_loop_il(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int taps, int dil,
+                                             const char* tile, int rowbytes_rt, Swz sm, int colrow, int lq) {
+  using O = Op<T>;
+  using frag = typename O::frag;
+  constexpr int RING = kPF + 1;
+  static_assert(RING % 2 == 0, "the B double buffer needs an even ring");
+  const int rowbytes = RB ? RB : rowbytes_rt;
+  frag ar[RING][MF];
+  frag bf[2][NF];
+  const int last = nIt - 1;
+#pragma unroll
+  for (int u = 0; u < kPF; ++u) {
+    const int idx = u < last ? u : last;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)idx * MF + m) * 64];
+  }
+  int pf = kPF;
+  int tap = 0, ks = 0;
+  auto read_b = [&](frag (&dst)[NF]) {
+    const int row0 = tap * dil + colrow;
+    const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
+#pragma unroll
+    for (int n = 0; n < NF; ++n) dst[n] = *reinterpret_cast<const frag*>(bp + n * 16 * rowbytes);
+    if (++ks == KS) { ks = 0; if (++tap == taps) tap = 0; }
+  };
+  read_b(bf[0]);
+  for (int it0 = 0; it0 < nIt; it0 += RING) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      if (it0 + u < nIt) {                                          // wave-uniform
+        const int pfi = pf < last ? pf : last;
+        ++pf;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pfi * MF + m) * 64];
+        read_b(bf[(u + 1) & 1]);
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int m = 0; m < MF; ++m) acc[m][n] = O::mfma(ar[u][m], bf[u & 1][n], acc[m][n]);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);         // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, MF, 0);         // VMEM read (weights)
+#pragma unroll
+        for (int n = 0; n < NF - 1; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one LDS read ...
+          __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);       // ... under MF MFMAs
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  }
 }
 
 // WM waves along M, WN = 4/WM along the frames; block tile = [WM*MF*16 rows] x [WN*NF*16 frames].
@@ -432,8 +504,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // intermediate's HBM round trip and one staging pass; the price is NF+1 instead of NF column
 // fragments in GEMM1.  The residual stream is carried in the operand type (costs 0.35 dB).
 // NWV = waves per workgroup (4, or 8 with all of them along M: see wide_pair_layout in qvc_plan.h)
+//
+// One launch carries pair q of up to three independent ResBlock chains (PairArgs3): workgroup x works for chain
+// x % n.  The chains differ in kernel size, so the workgroups sharing a CU have different durations and drift out
+// of phase -- the memory phases (staging, epilogue) of one run under the GEMM phases of another.
+//
+// Rows are lane-packed (ConvDesc::lp): a lane's MF accumulator quads are 4*MF consecutive channels, so with an
+// even MF the intermediate goes to LDS and the residual / result move through memory in 16-byte pieces.
 template <typename T, int MF, int NF, int WM, int NWV>
-__global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
+__global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   using O = Op<T>;
   using frag = typename O::frag;
   using quad = typename O::quad;
@@ -443,44 +522,57 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
   constexpr int NF1 = NF + 1;
   constexpr int NT = WN * NF * 16;       // output frames per block
   constexpr int N1P = WN * NF1 * 16;     // intermediate frames computed per block (>= NT + 2*h2)
+  constexpr bool kWide = MF % 2 == 0;    // 8 consecutive channels per 16-byte piece
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
-  const int q0 = blockIdx.x * NT;
+  const int nj = A.n;
+  const int chain = nj > 1 ? (int)(blockIdx.x % (unsigned)nj) : 0;
+  const int q0 = (nj > 1 ? (int)(blockIdx.x / (unsigned)nj) : (int)blockIdx.x) * NT;
+  PairArgs a = A.p[0];                   // scalar selects: a dynamic index into the kernel arguments would go through scratch
+  if (chain == 1) a = A.p[1];
+  if (chain == 2) a = A.p[2];
   const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
   const int Rx = N1P + 2 * h1;           // staged rows; row 0 <-> frame q0 - h2 - h1
   const int rowbytes = a.CP * 2;
   const int cpr = a.CP >> 3;
   const Swz sm = swz_mode(cpr);
   const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
+  const int cb = wm * MF * 16 + lq * 4 * MF;   // first of this lane's 4*MF consecutive channels
 
-
-  if (!QVC_ABL(0)) {   // ---- stage lrelu(x)
+  if (!QVC_ABL(0)) {   // ---- stage lrelu(x): every load of the tile is in flight before the first conversion
+    // (no accumulator is live yet, so the registers are free: one memory round trip per tile instead of two)
     const int t_base = q0 - h2 - h1;
     const int total = Rx * cpr;
-    constexpr int kU = 8;
+    constexpr int kU = 16;
+    const int rstep = NTHR / cpr, cstep = NTHR - rstep * cpr;
     for (int base = tid; base < total; base += NTHR * kU) {
       uint4 v[kU];
-      int dst[kU];
+      const int r_0 = base / cpr, c_0 = base - r_0 * cpr;
+      int r = r_0, c8 = c_0;
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int idx = base + u * NTHR;
-        const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
-        const bool ok = idx < total && ti >= 0 && ti < a.T && (c8 * 8 < a.C);
         v[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (ok) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
-        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+        if (idx < total && ti >= 0 && ti < a.T && c8 * 8 < a.C) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
+        c8 += cstep; r += rstep;
+        if (c8 >= cpr) { c8 -= cpr; ++r; }
       }
+      r = r_0; c8 = c_0;
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (dst[u] >= 0) {
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * NTHR;
+        if (idx < total) {
           frag h; __builtin_memcpy(&h, &v[u], 16);
-          *reinterpret_cast<frag*>(smem + dst[u]) = lrelu8<T>(h, a.slope);
+          *reinterpret_cast<frag*>(smem + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = lrelu8<T>(h, a.slope);
         }
+        c8 += cstep; r += rstep;
+        if (c8 >= cpr) { c8 -= cpr; ++r; }
+      }
     }
   }
   __syncthreads();
@@ -493,25 +585,48 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
       for (int n = 0; n < NF1; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w1) + ((size_t)wm * a.nIt * MF) * 64 + lane;
     if (!QVC_ABL(1)) gemm_loop<T, MF, NF1, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF1 * 16) + lrow, lq, QVC_ROT(a.nIt));
+    float4 bias[MF];                     // the bias array is padded to WM*MF*16 entries (zeros past C)
+#pragma unroll
+    for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b1 + cb + m * 4);
     __syncthreads();                     // every wave is done reading the input tile
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      const int v = (wm * MF + m) * 16 + lq * 4;
-      if (v >= a.CP) continue;
-      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < a.C) bias = *reinterpret_cast<const float4*>(a.b1 + v);
+    for (int n = 0; n < NF1; ++n) {
+      const int jr = wn * (NF1 * 16) + n * 16 + lrow;            // intermediate row <-> frame q0 - h2 + jr
+      const int f = q0 - h2 + jr;
+      const bool inside = f >= 0 && f < a.T;                     // conv2 zero-pads outside [0, T)
+      char* rowp = smem + jr * rowbytes;
+      const int sw = swz(jr, sm);
+      if constexpr (kWide) {
 #pragma unroll
-      for (int n = 0; n < NF1; ++n) {
-        const int j = wn * (NF1 * 16) + n * 16 + lrow;          // intermediate row <-> frame q0 - h2 + j
-        const int f = q0 - h2 + j;
-        quad h;
-        if (f >= 0 && f < a.T && v < a.C) {                      // conv2 zero-pads outside [0, T)
-          h[0] = O::cvt(lrelu(acc[m][n][0] + bias.x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias.y, a.slope));
-          h[2] = O::cvt(lrelu(acc[m][n][2] + bias.z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias.w, a.slope));
-        } else {
-          h[0] = h[1] = h[2] = h[3] = (T)0.f;
+        for (int m = 0; m < MF; m += 2) {
+          const int v = cb + m * 4;                              // channels v .. v+7, one 16-byte chunk
+          if (v >= a.CP) continue;
+          frag h;
+          if (inside && v < a.C) {
+            h[0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope));
+            h[2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope));
+            h[4] = O::cvt(lrelu(acc[m + 1][n][0] + bias[m + 1].x, a.slope)); h[5] = O::cvt(lrelu(acc[m + 1][n][1] + bias[m + 1].y, a.slope));
+            h[6] = O::cvt(lrelu(acc[m + 1][n][2] + bias[m + 1].z, a.slope)); h[7] = O::cvt(lrelu(acc[m + 1][n][3] + bias[m + 1].w, a.slope));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (T)0.f;
+          }
+          *reinterpret_cast<frag*>(rowp + (((v >> 3) ^ sw) << 4)) = h;
         }
-        *reinterpret_cast<quad*>(smem + j * rowbytes + (((v >> 3) ^ swz(j, sm)) << 4) + (v & 7) * 2) = h;
+      } else {
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const int v = cb + m * 4;
+          if (v >= a.CP) continue;
+          quad h;
+          if (inside && v < a.C) {
+            h[0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope));
+            h[2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope));
+          } else {
+            h[0] = h[1] = h[2] = h[3] = (T)0.f;
+          }
+          *reinterpret_cast<quad*>(rowp + (((v >> 3) ^ sw) << 4) + (v & 7) * 2) = h;
+        }
       }
     }
   }
@@ -525,42 +640,297 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs a) {
       for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
     if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, 1, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
+    float4 bias[MF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b2 + cb + m * 4);
+    const T* xres = static_cast<const T*>(a.x) + (size_t)b * a.bs;
+    T* yb = static_cast<T*>(a.y) + (size_t)b * a.bs;
+    const int qw = q0 + wn * (NF * 16) + lrow;
     // All residual loads go out before the first store: x and y may alias as far as the compiler knows, so a
     // load-add-store per fragment compiles to load, s_waitcnt vmcnt(0), store -- MF*NF serialised memory round
     // trips at the tail of every workgroup (seen in the ISA; it was a third of the launch time).
-    quad rr[MF][NF];
+    if constexpr (kWide) {
+      uint4 rr[MF / 2][NF];
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      const int v = (wm * MF + m) * 16 + lq * 4;
+      for (int m = 0; m < MF; m += 2) {
+        const int v = cb + m * 4;
 #pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        const int q = q0 + wn * (NF * 16) + n * 16 + lrow;
-        const bool ok = v < a.C && q < a.T && !QVC_ABL(3);
-        const size_t off = (size_t)b * a.bs + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0);
-        rr[m][n] = *reinterpret_cast<const quad*>(static_cast<const T*>(a.x) + off);
+        for (int n = 0; n < NF; ++n) {
+          const int q = qw + n * 16;
+          const bool ok = v < a.C && q < a.T && !QVC_ABL(3);
+          rr[m / 2][n] = *reinterpret_cast<const uint4*>(xres + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0));
+        }
       }
-    }
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      const int v = (wm * MF + m) * 16 + lq * 4;
-      if (v >= a.C || (QVC_ABL(3) && acc[0][0][0] != 12345.f)) continue;
-      const float4 bias = *reinterpret_cast<const float4*>(a.b2 + v);
+      for (int m = 0; m < MF; m += 2) {
+        const int v = cb + m * 4;
+        if (v >= a.C || (QVC_ABL(3) && acc[0][0][0] != 12345.f)) continue;
 #pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        const int q = q0 + wn * (NF * 16) + n * 16 + lrow;
-        if (q >= a.T) continue;
-        const size_t off = (size_t)b * a.bs + (size_t)q * a.C + v;
-        const quad r4 = rr[m][n];
-        float4 val = make_float4(acc[m][n][0] + bias.x + (float)r4[0], acc[m][n][1] + bias.y + (float)r4[1],
-                                 acc[m][n][2] + bias.z + (float)r4[2], acc[m][n][3] + bias.w + (float)r4[3]);
-        quad h;
-        h[0] = O::cvt(val.x); h[1] = O::cvt(val.y); h[2] = O::cvt(val.z); h[3] = O::cvt(val.w);
-        *reinterpret_cast<quad*>(static_cast<T*>(a.y) + off) = h;
+        for (int n = 0; n < NF; ++n) {
+          const int q = qw + n * 16;
+          if (q >= a.T) continue;
+          frag r8; __builtin_memcpy(&r8, &rr[m / 2][n], 16);
+          frag h;
+          h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
+          h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r8[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r8[3]);
+          h[4] = O::cvt(acc[m + 1][n][0] + bias[m + 1].x + (float)r8[4]); h[5] = O::cvt(acc[m + 1][n][1] + bias[m + 1].y + (float)r8[5]);
+          h[6] = O::cvt(acc[m + 1][n][2] + bias[m + 1].z + (float)r8[6]); h[7] = O::cvt(acc[m + 1][n][3] + bias[m + 1].w + (float)r8[7]);
+          *reinterpret_cast<frag*>(yb + (size_t)q * a.C + v) = h;
+        }
+      }
+    } else {
+      quad rr[MF][NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const int v = cb + m * 4;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          const int q = qw + n * 16;
+          const bool ok = v < a.C && q < a.T && !QVC_ABL(3);
+          rr[m][n] = *reinterpret_cast<const quad*>(xres + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0));
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const int v = cb + m * 4;
+        if (v >= a.C || (QVC_ABL(3) && acc[0][0][0] != 12345.f)) continue;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          const int q = qw + n * 16;
+          if (q >= a.T) continue;
+          const quad r4 = rr[m][n];
+          quad h;
+          h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r4[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r4[1]);
+          h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r4[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r4[3]);
+          *reinterpret_cast<quad*>(yb + (size_t)q * a.C + v) = h;
+        }
       }
     }
   }
 }
 
+
+// ------------------------------------------------------------------ persistent fused ResBlock1 pair
+// The same math as rbpair_kernel, restructured so that NO memory phase is exposed ("pair kernel"):
+//   * one 4-wave workgroup per CU (one wave per SIMD, up to 512 registers each) walks a static list of tiles
+//     (chain, utterance, 16*NF frames);
+//   * the NEXT tile's rows are fetched into registers while GEMM2 of the current tile runs (issue early, write to
+//     LDS late) -- the CU's vector-memory path returns data in order, so loads that miss to HBM delay every later
+//     L2-hit weight load of the CU; the weight ring is therefore kPFA k-steps deep (about 2 us of MFMA work), which
+//     rides through an HBM round trip, instead of the 3 k-steps that cover an L2 hit;
+//   * the raw residual rows of the tile stay in a second LDS region, so x is read from memory exactly once and
+//     the epilogue is acc + bias + LDS residual -> 16-byte stores, which drain under the next tile's GEMM1.
+// Barriers are raw s_barrier + lgkmcnt(0): they order LDS traffic and leave global loads / stores in flight.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+constexpr int kPairPFA = 11;             // A-fragment prefetch depth of the persistent pair kernel (k-steps)
+
+template <typename T, int MF, int NF, int PFU, int RB>
+__global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 A, const int tiles, const int batch, const int tile_rows) {
+  using O = Op<T>;
+  using frag = typename O::frag;
+  using quad = typename O::quad;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHR = 256;
+  constexpr int NF1 = NF + 1;
+  constexpr int NT = NF * 16;            // output frames per tile
+  constexpr int N1P = NF1 * 16;          // intermediate frames computed per tile (>= NT + 2*h2)
+  constexpr bool kWide = MF % 2 == 0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int CP = RB ? RB / 2 : A.p[0].CP, C = A.p[0].C, T_ = A.p[0].T;
+  const int rowbytes = CP * 2;
+  const int cpr = CP >> 3;
+  const Swz sm = swz_mode(cpr);
+  char* tileb = smem;                                  // activated input tile / intermediate tile
+  char* resb = smem + (size_t)tile_rows * rowbytes;    // raw residual rows of the current tile [NT]
+  const int cb = wm * MF * 16 + lq * 4 * MF;           // first of this lane's 4*MF consecutive channels
+  const int per_chain = tiles * batch;
+  const int items = A.n * per_chain;
+  const int rstep = NTHR / cpr, cstep = NTHR - rstep * cpr;
+  const int r_0 = tid / cpr, c_0 = tid - r_0 * cpr;
+
+  // item -> (chain arguments, utterance, first frame); scalar selects, no dynamic index into the kernel arguments
+  auto decode = [&](int it, PairArgs& a, int& b, int& q0) {
+    const int chain = it / per_chain, rem = it - chain * per_chain;
+    b = rem / tiles;
+    q0 = (rem - b * tiles) * NT;
+    a = A.p[0];
+    if (chain == 1) a = A.p[1];
+    if (chain == 2) a = A.p[2];
+  };
+
+  uint4 pf[PFU];                                       // the next tile on its way from memory to LDS
+  // Loads are unconditional from a clamped (always valid) address and the out-of-range rows are zeroed when the
+  // tile is written: a conditional load per element would put an exec-mask branch around each of them.
+  auto issue_loads = [&](const PairArgs& a, int b, int q0) {
+    const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
+    const int t_base = q0 - h2 - h1;
+    const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
+    const int cmax = (C >> 3) - 1;
+    int r = r_0, c8 = c_0;
+#pragma unroll
+    for (int u = 0; u < PFU; ++u) {
+      const int ti = min(max(t_base + r, 0), T_ - 1);
+      if (QVC_ABL(0)) pf[u] = make_uint4(0x3c003c00u, 0xbc00bc00u, 0x3c003c00u, 0xbc00bc00u);
+      else pf[u] = *reinterpret_cast<const uint4*>(xb + (ti * C + min(c8, cmax) * 8));
+      c8 += cstep; r += rstep;
+      if (c8 >= cpr) { c8 -= cpr; ++r; }
+    }
+  };
+  auto write_tile = [&](const PairArgs& a, int q0) {
+    const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
+    const int total = (N1P + 2 * h1) * cpr;
+    const int t_base = q0 - h2 - h1;
+    int r = r_0, c8 = c_0;
+#pragma unroll
+    for (int u = 0; u < PFU; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < total) {
+        const int ti = t_base + r;
+        uint4 raw = pf[u];
+        if (ti < 0 || ti >= T_ || c8 * 8 >= C) raw = make_uint4(0u, 0u, 0u, 0u);
+        frag h; __builtin_memcpy(&h, &raw, 16);
+        *reinterpret_cast<frag*>(tileb + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = lrelu8<T>(h, a.slope);
+        const int rr = r - h1 - h2;                    // tile row of frame q0 is h1 + h2
+        if (rr >= 0 && rr < NT) *reinterpret_cast<uint4*>(resb + rr * rowbytes + ((c8 ^ swz(rr, sm)) << 4)) = raw;
+      }
+      c8 += cstep; r += rstep;
+      if (c8 >= cpr) { c8 -= cpr; ++r; }
+    }
+  };
+
+  int it = blockIdx.x;
+  if (it >= items) return;
+  PairArgs a; int b, q0;
+  decode(it, a, b, q0);
+  issue_loads(a, b, q0);
+  write_tile(a, q0);
+  lds_barrier();
+
+  for (;;) {
+    const int nxt = it + gridDim.x;
+    const bool has_next = nxt < items;                 // wave-uniform (scalar)
+    {   // ---- GEMM1 over N1P frames, then bias + lrelu -> intermediate tile (in place of the input tile)
+      f32x4 acc[MF][NF1];
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF1; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const frag* ap = static_cast<const frag*>(a.w1) + ((size_t)wm * a.nIt * MF) * 64 + lane;
+      if (!QVC_ABL(1)) gemm_loop_il<T, MF, NF1, kPairPFA, RB>(acc, ap, a.nIt, a.KS, a.k, a.dil, tileb, rowbytes, sm, lrow, lq);
+      float4 bias[MF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b1 + cb + m * 4);
+      const int h2 = (a.k - 1) / 2;
+      lds_barrier();                                   // every wave is done reading the input tile
+#pragma unroll
+      for (int n = 0; n < NF1; ++n) {
+        const int jr = n * 16 + lrow;                  // intermediate row <-> frame q0 - h2 + jr
+        const int f = q0 - h2 + jr;
+        const bool inside = f >= 0 && f < T_;          // conv2 zero-pads outside [0, T)
+        char* rowp = tileb + jr * rowbytes;
+        const int sw = swz(jr, sm);
+        if constexpr (kWide) {
+#pragma unroll
+          for (int m = 0; m < MF; m += 2) {
+            const int v = cb + m * 4;
+            if (v >= CP) continue;
+            frag h;
+            if (inside && v < C) {
+              h[0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope));
+              h[2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope));
+              h[4] = O::cvt(lrelu(acc[m + 1][n][0] + bias[m + 1].x, a.slope)); h[5] = O::cvt(lrelu(acc[m + 1][n][1] + bias[m + 1].y, a.slope));
+              h[6] = O::cvt(lrelu(acc[m + 1][n][2] + bias[m + 1].z, a.slope)); h[7] = O::cvt(lrelu(acc[m + 1][n][3] + bias[m + 1].w, a.slope));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) h[e] = (T)0.f;
+            }
+            *reinterpret_cast<frag*>(rowp + (((v >> 3) ^ sw) << 4)) = h;
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const int v = cb + m * 4;
+            if (v >= CP) continue;
+            quad h;
+            if (inside && v < C) {
+              h[0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope));
+              h[2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope));
+            } else {
+              h[0] = h[1] = h[2] = h[3] = (T)0.f;
+            }
+            *reinterpret_cast<quad*>(rowp + (((v >> 3) ^ sw) << 4) + (v & 7) * 2) = h;
+          }
+        }
+      }
+    }
+    lds_barrier();
+
+    if (has_next) {                                    // the next tile starts its trip from memory under GEMM2
+      PairArgs an; int bn, q0n;                        // (decoded again after GEMM2: cheaper than holding them in SGPRs)
+      decode(nxt, an, bn, q0n);
+      issue_loads(an, bn, q0n);
+    }
+
+    {   // ---- GEMM2 over NT frames (dilation 1) + bias + residual (from LDS) -> y
+      f32x4 acc[MF][NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
+      if (!QVC_ABL(2)) gemm_loop_il<T, MF, NF, kPairPFA, RB>(acc, ap, a.nIt, a.KS, a.k, 1, tileb, rowbytes, sm, lrow, lq);
+      float4 bias[MF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b2 + cb + m * 4);
+      T* yb = static_cast<T*>(a.y) + (size_t)b * a.bs;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int jr = n * 16 + lrow;
+        const int q = q0 + jr;
+        const char* rrow = resb + jr * rowbytes;
+        const int sw = swz(jr, sm);
+        if constexpr (kWide) {
+#pragma unroll
+          for (int m = 0; m < MF; m += 2) {
+            const int v = cb + m * 4;
+            if (v >= C || q >= T_) continue;
+            const frag r8 = *reinterpret_cast<const frag*>(rrow + (((v >> 3) ^ sw) << 4));
+            frag h;
+            h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
+            h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r8[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r8[3]);
+            h[4] = O::cvt(acc[m + 1][n][0] + bias[m + 1].x + (float)r8[4]); h[5] = O::cvt(acc[m + 1][n][1] + bias[m + 1].y + (float)r8[5]);
+            h[6] = O::cvt(acc[m + 1][n][2] + bias[m + 1].z + (float)r8[6]); h[7] = O::cvt(acc[m + 1][n][3] + bias[m + 1].w + (float)r8[7]);
+            if (!QVC_ABL(3) || h[0] == (T)12345.f) *reinterpret_cast<frag*>(yb + (size_t)q * C + v) = h;
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const int v = cb + m * 4;
+            if (v >= C || q >= T_) continue;
+            const quad r4 = *reinterpret_cast<const quad*>(rrow + (((v >> 3) ^ sw) << 4) + (v & 7) * 2);
+            quad h;
+            h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r4[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r4[1]);
+            h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r4[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r4[3]);
+            *reinterpret_cast<quad*>(yb + (size_t)q * C + v) = h;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    lds_barrier();                                     // every wave is done with the intermediate and the residual rows
+    it = nxt;
+    decode(it, a, b, q0);
+    write_tile(a, q0);
+    lds_barrier();
+  }
+}
 
 // ------------------------------------------------------------------ fused WaveNet layer
 // One wave per 16 channels (blockDim = HP/16 waves <= WV, see wn_layout in qvc_plan.h): wave w holds the tanh,
@@ -1073,19 +1443,25 @@ int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, 
 }
 
 // ---- fused pair: tile choice + dispatch
-inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
+inline TileChoice choose_pair_tile(const ConvDesc* ds, int n, int T, int batch) {
   static const int nfs[] = {2, 4, 5, 8, 10}; // measured at B=32, MF 4: NF 5 (2 workgroups/CU) beats 4 and 8 by 7-35 %
+  const ConvDesc& d = ds[0];
   const int NWV = block_waves(d);
   const int WN = NWV / d.WM;
-  const int halo1 = (d.taps - 1) * d.dil, rowbytes = d.CinP * 2;
+  int halo1 = 0;                              // the chains of a launch share one tile shape: size it for the widest halo
+  for (int i = 0; i < n; ++i) halo1 = std::max(halo1, (ds[i].taps - 1) * ds[i].dil);
+  const int rowbytes = d.CinP * 2;
   TileChoice best{0, 0, 0};
   double best_cost = 1e300;
   for (int NF : nfs) {
+#ifdef QVC_FORCE_NF
+    if (NF != QVC_FORCE_NF) continue;
+#endif
     if (d.MF * (NF + 1) * 4 > 160 || (NF == 10 && d.MF > 2)) continue;
     const size_t lds = (size_t)(WN * (NF + 1) * 16 + halo1) * rowbytes;
     if (lds > 160 * 1024) continue;
     const int NT = WN * NF * 16;
-    const long blocks = (long)ceil_div(T, NT) * batch;
+    const long blocks = (long)ceil_div(T, NT) * batch * n;
     // workgroups that can share a CU: 2 x 4 waves or 1 x 8 waves (two waves per SIMD either way)
     const int bpc = NWV == 8 ? 1 : (int)std::min<size_t>(2, (160 * 1024) / lds);
     const long rounds = (blocks + 256L * bpc - 1) / (256L * bpc);
@@ -1099,18 +1475,18 @@ inline TileChoice choose_pair_tile(const ConvDesc& d, int T, int batch) {
 }
 
 template <typename T, int MF, int NF, int WM, int NWV>
-inline int launch_pair_one(const PairArgs& a, int batch, size_t lds, hipStream_t stream) {
+inline int launch_pair_one(const PairArgs3& a, int batch, size_t lds, hipStream_t stream) {
   auto kern = rbpair_kernel<T, MF, NF, WM, NWV>;
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   constexpr int NT = (NWV / WM) * NF * 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, NT), (unsigned)batch), dim3(NWV * 64), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ceil_div(a.p[0].T, NT) * a.n), (unsigned)batch), dim3(NWV * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
 template <typename T, int MF, int WM, int NWV>
-inline int launch_pair_nf(const ConvDesc& d, const PairArgs& a, int batch, hipStream_t stream, int* nf_out) {
-  const TileChoice tc = choose_pair_tile(d, a.T, batch);
+inline int launch_pair_nf(const ConvDesc* ds, const PairArgs3& a, int batch, hipStream_t stream, int* nf_out) {
+  const TileChoice tc = choose_pair_tile(ds, a.n, a.p[0].T, batch);
   if (nf_out) *nf_out = tc.NF;
   switch (tc.NF) {
     case 2: return launch_pair_one<T, MF, 2, WM, NWV>(a, batch, tc.lds, stream);
@@ -1123,20 +1499,75 @@ inline int launch_pair_nf(const ConvDesc& d, const PairArgs& a, int batch, hipSt
   return QVC_ERR_BAD_CONFIG;
 }
 
+// ---- persistent pair kernel: one workgroup per CU walks the tile list (see rbpair_persist_kernel)
+inline int device_cu_count() {
+  static std::atomic<int> cached[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int n = cached[dev & 31].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+  cached[dev & 31].store(n, std::memory_order_relaxed);
+  return n;
+}
+
+constexpr int kPersistPFU = 16;          // 16-byte loads per thread that carry the next tile (256 threads x 16 x 16 B = 64 KiB)
+
+template <typename T, int MF, int NF>
+inline int launch_pair_persist(const ConvDesc* ds, const PairArgs3& a, int batch, hipStream_t stream, bool* taken) {
+  *taken = false;
+  const ConvDesc& d = ds[0];
+  int halo1 = 0;
+  for (int i = 0; i < a.n; ++i) halo1 = std::max(halo1, (ds[i].taps - 1) * ds[i].dil);
+  const int tile_rows = (NF + 1) * 16 + halo1;
+  const int cpr = d.CinP >> 3;
+  const size_t lds = (size_t)(tile_rows + NF * 16) * d.CinP * 2;
+  const int tiles = ceil_div(a.p[0].T, NF * 16);
+  const long items = (long)tiles * batch * a.n;
+  int cus = device_cu_count();
+  const int mode = pair_persist_mode();
+  if (pair_grid_cap() > 0) cus = std::min(cus, pair_grid_cap());
+  // worth it when every CU gets several tiles (the first one's load is exposed, the others ride under GEMM2)
+  if (cus <= 0 || mode == 0 || (mode == 1 && items < 3L * cus) || lds > 160 * 1024 || (long)tile_rows * cpr > 256L * kPersistPFU) return QVC_OK;
+  *taken = true;
+  const dim3 grid((unsigned)std::min<long>(items, cus));
+  if (d.CinP == 128) {                                     // the shipped stage-2 width: row pitch known at compile time
+    auto kern = rbpair_persist_kernel<T, MF, NF, kPersistPFU, 256>;
+    static std::atomic<uint32_t> lds_ok{0};
+    if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, tiles, batch, tile_rows);
+  } else {
+    auto kern = rbpair_persist_kernel<T, MF, NF, kPersistPFU, 0>;
+    static std::atomic<uint32_t> lds_ok{0};
+    if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, tiles, batch, tile_rows);
+  }
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
+
 template <typename T>
-int launch_pair_typed(const ConvDesc& d, const PairArgs& a, int batch, void* stream_v, int* nf_out) {
+int launch_pair_typed(const ConvDesc* ds, const PairArgs3& a, int batch, void* stream_v, int* nf_out) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const ConvDesc& d = ds[0];
+  if (d.WM == 4 && pair_persist_mode() != 0) {
+    bool taken = false;
+    int st = QVC_OK;
+    if (d.MF == 2) st = launch_pair_persist<T, 2, 10>(ds, a, batch, stream, &taken);
+    else if (d.MF == 1) st = launch_pair_persist<T, 1, 10>(ds, a, batch, stream, &taken);
+    if (taken || st != QVC_OK) { if (nf_out) *nf_out = 110; return st; }
+  }
   switch (d.WM * 10 + d.MF) {
-    case 41: return launch_pair_nf<T, 1, 4, 4>(d, a, batch, stream, nf_out);
-    case 42: return launch_pair_nf<T, 2, 4, 4>(d, a, batch, stream, nf_out);
-    case 43: return launch_pair_nf<T, 3, 4, 4>(d, a, batch, stream, nf_out);
-    case 44: return launch_pair_nf<T, 4, 4, 4>(d, a, batch, stream, nf_out);
-    case 23: return launch_pair_nf<T, 3, 2, 4>(d, a, batch, stream, nf_out);
-    case 24: return launch_pair_nf<T, 4, 2, 4>(d, a, batch, stream, nf_out);
-    case 14: return launch_pair_nf<T, 4, 1, 4>(d, a, batch, stream, nf_out);
-    case 82: return launch_pair_nf<T, 2, 8, 8>(d, a, batch, stream, nf_out);
-    case 83: return launch_pair_nf<T, 3, 8, 8>(d, a, batch, stream, nf_out);
-    case 84: return launch_pair_nf<T, 4, 8, 8>(d, a, batch, stream, nf_out);
+    case 41: return launch_pair_nf<T, 1, 4, 4>(ds, a, batch, stream, nf_out);
+    case 42: return launch_pair_nf<T, 2, 4, 4>(ds, a, batch, stream, nf_out);
+    case 43: return launch_pair_nf<T, 3, 4, 4>(ds, a, batch, stream, nf_out);
+    case 44: return launch_pair_nf<T, 4, 4, 4>(ds, a, batch, stream, nf_out);
+    case 23: return launch_pair_nf<T, 3, 2, 4>(ds, a, batch, stream, nf_out);
+    case 24: return launch_pair_nf<T, 4, 2, 4>(ds, a, batch, stream, nf_out);
+    case 14: return launch_pair_nf<T, 4, 1, 4>(ds, a, batch, stream, nf_out);
+    case 82: return launch_pair_nf<T, 2, 8, 8>(ds, a, batch, stream, nf_out);
+    case 83: return launch_pair_nf<T, 3, 8, 8>(ds, a, batch, stream, nf_out);
+    case 84: return launch_pair_nf<T, 4, 8, 8>(ds, a, batch, stream, nf_out);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }
@@ -1148,8 +1579,17 @@ template <typename T, int NF, int WV>
 inline int launch_wn_one(const WnArgs& a, int waves, int batch, hipStream_t stream) {
   const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
   dim3 grid((unsigned)ceil_div(a.T, NF * 16), (unsigned)batch), block((unsigned)waves * 64);
-  if (a.last) hipLaunchKernelGGL((wn_layer_kernel<T, NF, true, WV>), grid, block, lds, stream, a);
-  else hipLaunchKernelGGL((wn_layer_kernel<T, NF, false, WV>), grid, block, lds, stream, a);
+  // hidden = 256 with 64-frame tiles needs (64 + taps-1 + 64) * 512 B > 64 KiB of dynamic LDS: opt in per device
+  static std::atomic<uint32_t> lds_ok_last{0}, lds_ok_mid{0};
+  if (a.last) {
+    auto kern = wn_layer_kernel<T, NF, true, WV>;
+    if (lds > 64 * 1024 && !allow_big_lds(lds_ok_last, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  } else {
+    auto kern = wn_layer_kernel<T, NF, false, WV>;
+    if (lds > 64 * 1024 && !allow_big_lds(lds_ok_mid, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 

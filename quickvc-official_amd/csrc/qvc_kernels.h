@@ -55,6 +55,14 @@ struct PairArgs {
   void* y = nullptr;
 };
 
+// Up to three INDEPENDENT pairs in one launch: pair q of the three ResBlocks of a stage (kernel sizes 3 / 7 / 11).
+// Workgroup x serves chain x % n, tile x / n, so the workgroups that share a CU have different durations and drift
+// out of phase: one's staging / epilogue (memory) runs under another's GEMMs (MFMA).  All chains share T, C, CP.
+struct PairArgs3 {
+  PairArgs p[3];
+  int32_t n = 1;
+};
+
 // One fused WaveNet layer (modules.py:87-112): k-tap conv h->2h + conditioning + tanh*sigmoid gate, then the
 // 1x1 h->2h whose first half is added to the residual stream x and second half to the skip accumulator
 // (all of it to the accumulator on the last layer).  x is ping-ponged (x_in -> x_out) because neighbouring
@@ -126,9 +134,18 @@ struct SpkEmbedArgs {   // relu(linear(h)) / ||.||, mean over an utterance's par
   int32_t utterances, n_part, H;
 };
 
+// Developer / test switches of the pair launcher (process-wide, read from the environment on first use):
+//   QVC_PAIR_PERSIST = 0 (default): never use the persistent pair kernel; 1: when every CU gets >= 3 tiles;
+//                      2: whenever the layout supports it (tests: small shapes still exercise it)
+//   QVC_PAIR_GRID    = N: at most N persistent workgroups (tests: makes a workgroup walk several tiles on tiny inputs)
+int& pair_persist_mode();
+int& pair_grid_cap();
+
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
+// n pairs (1..3) of equal shape class in one launch; d1[i] / d2[i] are chain i's convs
+int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 bool wn_stack_supported(const ConvDesc& din, int layers);
 int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dtype, void* stream);
 int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
@@ -140,6 +157,6 @@ int launch_tail(const TailArgs& a, void* stream);
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
 template <typename T> int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream);
 template <typename T> int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream, int* nf_out);
-template <typename T> int launch_pair_typed(const ConvDesc& d1, const PairArgs& a, int batch, void* stream, int* nf_out);
+template <typename T> int launch_pair_typed(const ConvDesc* d1, const PairArgs3& a, int batch, void* stream, int* nf_out);
 
 }  // namespace qvc

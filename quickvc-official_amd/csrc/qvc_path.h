@@ -8,12 +8,14 @@
 //
 // A backend provides:  int conv(const ConvDesc&, const ConvArgs&, int batch, int epi, int dtype);
 //                      int pair(const ConvDesc&, const ConvDesc&, const PairArgs&, int batch, int dtype);
+//                      int pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3&, int batch, int dtype);
 //                      int wn(const ConvDesc& in, const ConvDesc& rs, const WnArgs&, int batch, int dtype);
 //                      int gemv(const GemvArgs&); int sample(const SampleArgs&);
 //                      int tail(const TailArgs&); int zero(void* ptr, size_t bytes);
 //                      void fork(int n); void branch(int j); void branch_done(int j);
 //                      void wait_branch_done(int j); void join(int n);   (stream fork/join; no-ops on one stream)
 #pragma once
+#include <algorithm>
 #include "qvc_kernels.h"
 
 namespace qvc {
@@ -247,28 +249,62 @@ struct Path {
         a.y16 = wsp<void>(W.u[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;   // raw, operand type
         conv(st.up, a);
       }
-      // The ResBlocks of a stage are independent until their mean: branch j runs on stream j (when
-      // the backend has auxiliary streams; otherwise the same order on one stream).  The last pair of
-      // each branch accumulates into the MRF mean, so those launches are chained j-1 -> j.
+      // The ResBlocks of a stage are independent until their mean.  Pair q of all three chains goes out as ONE
+      // launch (workgroups of chains with different kernel sizes interleave on the CUs, see rbpair_kernel); a stage
+      // whose pairs cannot run fused falls back to one launch per conv, optionally on parallel branches (streams).
       const int NB = c.n_resblocks;
-      be.fork(NB);                                   // branches wait for everything enqueued so far
       std::vector<const void*> src((size_t)NB, wsp<void>(W.u[i]));
+      auto pair_args = [&](int j, int q, void* dst) {
+        const ConvDesc& d1 = st.c1[(size_t)j * 3 + q];
+        const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
+        PairArgs pa;
+        pa.x = src[(size_t)j]; pa.bs = bs; pa.T = t_out; pa.C = ch; pa.CP = d1.CinP;
+        pa.w1 = blob + d1.w_off; pa.b1 = reinterpret_cast<const float*>(blob + d1.b_off);
+        pa.w2 = blob + d2.w_off; pa.b2 = reinterpret_cast<const float*>(blob + d2.b_off);
+        pa.k = d1.taps; pa.dil = d1.dil; pa.KS = d1.KS(); pa.nIt = d1.nIt(); pa.slope = 0.1f;
+        pa.y = dst;
+        return pa;
+      };
+      bool fused = NB <= 3;
+      for (int j = 0; j < NB && fused; ++j)
+        for (int q = 0; q < 3; ++q) {
+          const ConvDesc& d1 = st.c1[(size_t)j * 3 + q];
+          const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
+          fused = fused && pair_supported(d1, d2) && d1.lp && d2.lp && d1.MF == st.c1[0].MF && d1.WM == st.c1[0].WM;
+        }
+      // One launch for the three chains only where two workgroups share a CU (4-wave layouts).  With one 8-wave
+      // workgroup per CU (>= 256 channels) the mixed durations just unbalance the CUs: measured 261 us for the
+      // fused launch against 226 us for three launches at stage 1 of the shipped config.
+      const int per_launch = block_waves(st.c1[0]) == kWaves ? NB : 1;
+      if (fused) {
+        for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
+          // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
+          // consumer (next up-sampler / conv_post) while it stages its input, so nothing is accumulated here
+          PairArgs3 a3; a3.n = per_launch;
+          ConvDesc d1s[3], d2s[3];
+          // the chain with the largest kernel first: its workgroups are the longest, so they should start earliest
+          int order[3] = {j0, j0 + 1, j0 + 2};
+          std::sort(order, order + per_launch, [&](int x, int y) { return st.c1[(size_t)x * 3 + q].nIt() > st.c1[(size_t)y * 3 + q].nIt(); });
+          for (int s_ = 0; s_ < per_launch; ++s_) {
+            const int j = order[s_];
+            void* dst = q == 1 ? wsp<void>(W.rb[i][(size_t)j]) : wsp<void>(W.ra[i][(size_t)j]);
+            a3.p[s_] = pair_args(j, q, dst);
+            d1s[s_] = st.c1[(size_t)j * 3 + q]; d2s[s_] = st.c2[(size_t)j * 3 + q];
+            src[(size_t)j] = dst;
+          }
+          if (status == QVC_OK) status = be.pair3(d1s, d2s, a3, B, dtype());
+        }
+      } else {
+      be.fork(NB);                                   // branches wait for everything enqueued so far
       for (int q = 0; q < 3; ++q)
         for (int j = 0; j < NB; ++j) {
           be.branch(j);
           const ConvDesc& d1 = st.c1[(size_t)j * 3 + q];
           const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
-          // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
-          // consumer (next up-sampler / conv_post) while it stages its input, so nothing is accumulated here
           void* dst = q == 1 ? wsp<void>(W.rb[i][(size_t)j]) : wsp<void>(W.ra[i][(size_t)j]);
           const bool last = q == 2;
-          if (pair_supported(d1, d2)) {
-            PairArgs pa;
-            pa.x = src[(size_t)j]; pa.bs = bs; pa.T = t_out; pa.C = ch; pa.CP = d1.CinP;
-            pa.w1 = blob + d1.w_off; pa.b1 = reinterpret_cast<const float*>(blob + d1.b_off);
-            pa.w2 = blob + d2.w_off; pa.b2 = reinterpret_cast<const float*>(blob + d2.b_off);
-            pa.k = d1.taps; pa.dil = d1.dil; pa.KS = d1.KS(); pa.nIt = d1.nIt(); pa.slope = 0.1f;
-            pa.y = dst;
+          if (pair_supported(d1, d2) && d1.lp && d2.lp) {
+            const PairArgs pa = pair_args(j, q, dst);
             if (status == QVC_OK) status = be.pair(d1, d2, pa, B, dtype());
           } else {
             void* xt = wsp<char>(W.xt[i]) + (size_t)j * (size_t)B * (size_t)bs * 2;
@@ -292,6 +328,7 @@ struct Path {
           src[(size_t)j] = dst;
         }
       be.join(NB);                                   // main stream continues when every branch is done
+      }
       t_in = t_out; ch_in = ch;
     }
     {   // lrelu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post(k7)

@@ -35,6 +35,8 @@ struct ConvDesc {
   int32_t Cout = 0;     // real output channels (M = up_s * Cout)
   int32_t ksize = 1;    // kernel size of the original (transposed) conv, for FLOP accounting
   int32_t gau = 0;      // 1: rows permuted so that a wave owns tanh and sigmoid rows of the same channels
+  int32_t lp = 0;       // 1: "lane-packed" rows (fused ResBlock pairs): a lane's MF accumulator quads are 4*MF CONSECUTIVE
+                        //    channels, so the epilogues move 16 bytes per lane instead of 8 (see conv_row)
   int64_t w_off = 0;    // byte offset of the A stream
   int64_t b_off = 0;    // byte offset of the fp32 bias [MP]
   int32_t MP() const { return nchunk * WM * MF * 16; }
@@ -47,6 +49,12 @@ struct ConvDesc {
 // Row permutation of the A stream: packed position -> original output channel (or -1 = zero padding).
 // `wave` = the wave's index along M (0..WM-1).
 inline int conv_row(const ConvDesc& d, int chunk, int wave, int mf, int i) {
+  if (d.lp) {
+    // MFMA 16x16 output: lane (col, lq) holds rows lq*4 .. lq*4+3 of each fragment.  Row i of fragment mf carries
+    // channel base + (i/4)*4*MF + mf*4 + i%4, i.e. lane lq owns channels [base + lq*4*MF, base + (lq+1)*4*MF).
+    const int v = (chunk * d.WM + wave) * d.MF * 16 + (i >> 2) * 4 * d.MF + mf * 4 + (i & 3);
+    return v < d.M ? v : -1;
+  }
   if (!d.gau) {
     int v = ((chunk * d.WM + wave) * d.MF + mf) * 16 + i;
     return v < d.M ? v : -1;
@@ -107,6 +115,12 @@ inline void wide_pair_layout(ConvDesc& d1, ConvDesc& d2) {
   ConvDesc a = d1, b = d2;
   a.WM = b.WM = 8; a.MF = b.MF = d1.M / 128; a.nchunk = b.nchunk = 1;
   if (pair_supported(a, b)) { d1 = a; d2 = b; }
+}
+// Layout of the two convs of a ResBlock1 pair: the wide (8-wave) layout where it applies, and lane-packed rows
+// whenever the pair runs fused (the unfused fallback keeps natural row order for the generic conv kernel).
+inline void pair_layout(ConvDesc& d1, ConvDesc& d2) {
+  wide_pair_layout(d1, d2);
+  if (pair_supported(d1, d2)) { d1.lp = 1; d2.lp = 1; }
 }
 
 // WaveNet kernels (fused layer / whole stack): ONE WAVE PER 16 CHANNELS -- a workgroup of CinP/16 waves (12 at
@@ -201,6 +215,9 @@ inline int validate(const qvc_config& c) {
   for (int i = 0; i < c.n_ups; ++i) {
     int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
     if (bad(s < 1 || s > 16 || k < s || k > 64)) return QVC_ERR_BAD_CONFIG;
+    // models.py:335: padding (k-s+1-i)//2 with output_padding 1-i gives T_out = s*T_in only when k-s+1-i is even;
+    // the workspace carve-up, the tail and the output shape all assume s*T_in (and PyTorch rejects output_padding < 0)
+    if (bad((k - s + 1 - i) < 0 || (k - s + 1 - i) % 2 != 0 || i > 1)) return QVC_ERR_BAD_CONFIG;
     if (bad(ch % 2)) return QVC_ERR_BAD_CONFIG;
     ch /= 2;
     if (bad(ch % 8)) return QVC_ERR_BAD_CONFIG;
@@ -307,7 +324,7 @@ inline Plan build_plan(const qvc_config& c) {
       for (int q = 0; q < 3; ++q) {
         ConvDesc a = make_conv(ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilations[j][q]);
         ConvDesc b = make_conv(ch, ch, c.resblock_kernel_sizes[j], 1);
-        wide_pair_layout(a, b);
+        pair_layout(a, b);
         place(a); place(b);
         st.c1.push_back(a); st.c2.push_back(b);
       }

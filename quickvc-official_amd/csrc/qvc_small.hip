@@ -7,6 +7,7 @@
 //                          zero-stuffed intermediate, each post-conv frame read once (+halo).
 //   * fm_to_cm_kernel    : frame-major -> (B,C,T) for the unit-test conv entry point.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "qvc_launch_util.h"
 #include "qvc_kernels.h"
 
@@ -291,11 +292,30 @@ int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream,
   return QVC_ERR_BAD_ARG;
 }
 
-int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out) {
-  if (!pair_supported(d1, d2)) return QVC_ERR_BAD_CONFIG;
+int& pair_persist_mode() {
+  static int mode = [] { const char* e = std::getenv("QVC_PAIR_PERSIST"); return e ? std::atoi(e) : 0; }();
+  return mode;
+}
+int& pair_grid_cap() {
+  static int cap = [] { const char* e = std::getenv("QVC_PAIR_GRID"); return e ? std::atoi(e) : 0; }();
+  return cap;
+}
+
+int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype, void* stream, int* nf_out) {
+  if (a.n < 1 || a.n > 3) return QVC_ERR_BAD_ARG;
+  for (int i = 0; i < a.n; ++i) {
+    if (!pair_supported(d1[i], d2[i]) || !d1[i].lp || !d2[i].lp) return QVC_ERR_BAD_CONFIG;
+    if (d1[i].MF != d1[0].MF || d1[i].WM != d1[0].WM || d1[i].CinP != d1[0].CinP) return QVC_ERR_BAD_CONFIG;
+    if (a.p[i].T != a.p[0].T || a.p[i].C != a.p[0].C || a.p[i].CP != a.p[0].CP) return QVC_ERR_BAD_ARG;
+  }
   if (dtype == QVC_F16) return launch_pair_typed<_Float16>(d1, a, batch, stream, nf_out);
   if (dtype == QVC_BF16) return launch_pair_typed<__bf16>(d1, a, batch, stream, nf_out);
   return QVC_ERR_BAD_ARG;
+}
+
+int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out) {
+  PairArgs3 a3; a3.p[0] = a; a3.n = 1;
+  return launch_pair3(&d1, &d2, a3, batch, dtype, stream, nf_out);
 }
 
 }  // namespace qvc

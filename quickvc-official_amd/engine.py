@@ -8,6 +8,7 @@ work (the LSTM speaker encoder) and can be captured in a ``torch.cuda.CUDAGraph`
 from __future__ import annotations
 
 import ctypes
+import functools
 from typing import Dict, Optional
 
 import torch
@@ -19,6 +20,16 @@ def _aligned_empty(nbytes: int, device) -> torch.Tensor:
     raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
     shift = (-raw.data_ptr()) % 256
     return raw[shift:shift + nbytes]
+
+
+def _on_device(fn):
+    """Run a method with the engine's GPU as the current device: the library keys per-device state (the opt-in for
+    more than 64 KiB of dynamic LDS) on hipGetDevice(), and a process may drive several GPUs."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 class QvcEngine:
@@ -67,6 +78,14 @@ class QvcEngine:
     def load_blob_(self, blob: torch.Tensor) -> None:
         self.blob.copy_(blob)
 
+    def alloc_workspace(self, batch: int, frames: int) -> torch.Tensor:
+        """A private workspace for (batch, frames).  Anything that bakes workspace pointers into a captured graph
+        must own the buffer it captured (the shared one below is replaced when a larger request arrives)."""
+        n = int(self.lib.qvc_workspace_bytes(ctypes.byref(self.cfg), batch, frames))
+        if n < 0:
+            L.check(self.lib, n, "qvc_workspace_bytes")
+        return _aligned_empty(n, self.device)
+
     def workspace(self, batch: int, frames: int) -> torch.Tensor:
         key = (batch, frames)
         if self._ws is None or self._ws_key != key:
@@ -82,9 +101,11 @@ class QvcEngine:
     def _f32(t: torch.Tensor, device) -> torch.Tensor:
         return t.to(device=device, dtype=torch.float32).contiguous()
 
+    @_on_device
     def infer_batch(self, unit: torch.Tensor, g: torch.Tensor, noise: torch.Tensor,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """unit (B,256,T), g (B,gin), noise (B,inter,T) -> (B,1,T*samples_per_frame) fp32."""
+                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """unit (B,256,T), g (B,gin), noise (B,inter,T) -> (B,1,T*samples_per_frame) fp32.
+        ``ws``: a caller-owned workspace from alloc_workspace(B, T) (graph owners); default = the shared one."""
         B, cu, T = unit.shape
         mc = self.model_config
         if cu != mc.get("unit_channels", 256) or g.shape != (B, mc["gin_channels"]) or \
@@ -93,7 +114,8 @@ class QvcEngine:
         unit, g, noise = (self._f32(t, self.device) for t in (unit, g, noise))
         if out is None:
             out = torch.empty(B, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
-        ws = self.workspace(B, T)
+        if ws is None:
+            ws = self.workspace(B, T)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         st = self.lib.qvc_infer_batch_ex(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
                                          noise.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), ws.numel(), stream,
@@ -101,6 +123,7 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_infer_batch")
         return out
 
+    @_on_device
     def speaker_embed(self, mel: torch.Tensor) -> torch.Tensor:
         """SpeakerEncoder.embed_utterance for a batch (models.py:528-546): mel (U, n_mel, F) -> g (U, gin)."""
         if mel.dim() != 3 or mel.shape[1] != int(self.cfg.n_mel_channels) or mel.shape[2] < 1:
@@ -125,6 +148,7 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_speaker_embed")
         return g
 
+    @_on_device
     def enc_q(self, spec: torch.Tensor, g: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
         """Posterior encoder, models.py:617: spec (B, spec_channels, T), g (B, gin), noise (B, inter, T) -> z [B][T][inter]."""
         B, cs, T = spec.shape
@@ -145,6 +169,7 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_enc_q")
         return z
 
+    @_on_device
     def flow_forward(self, z_fm: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
         """ResidualCouplingBlock.forward(reverse=False), models.py:618: z [B][T][inter] -> z_p (a new tensor)."""
         B, T, _ = z_fm.shape
@@ -156,6 +181,7 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_flow_forward")
         return z
 
+    @_on_device
     def infer_batch_timed(self, unit, g, noise, out=None, max_records: int = 512):
         """Same launches with per-launch HIP-event timing; returns (out, [dict(name, ms, flops, bytes)])."""
         B, _, T = unit.shape
@@ -174,6 +200,7 @@ class QvcEngine:
                           bytes=float(rec[i].bytes)) for i in range(min(n.value, max_records))]
 
     # ---- stage entry points (frame-major tensors), used by the stage-level parity tests
+    @_on_device
     def enc_p(self, unit, noise):
         B, _, T = unit.shape
         unit, noise = self._f32(unit, self.device), self._f32(noise, self.device)
@@ -185,6 +212,21 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_enc_p")
         return z
 
+    @_on_device
+    def wn_stack(self, which: int, x_fm, g=None):
+        """WN.forward (modules.py:69-114) of stack ``which`` (0 = enc_p.enc, 1+i = flow.flows[2i].enc): [B][T][hidden] -> same."""
+        B, T, _ = x_fm.shape
+        x = self._f32(x_fm, self.device)
+        gg = self._f32(g, self.device) if g is not None else None
+        out = torch.empty_like(x)
+        ws = self.workspace(B, T)
+        st = self.lib.qvc_wn_stack(ctypes.byref(self.cfg), self.blob.data_ptr(), int(which), x.data_ptr(),
+                                   gg.data_ptr() if gg is not None else None, out.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
+                                   torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_wn_stack")
+        return out
+
+    @_on_device
     def flow_reverse(self, z_fm, g):
         B, T, _ = z_fm.shape
         z = self._f32(z_fm, self.device).clone()
@@ -195,6 +237,7 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_flow_reverse")
         return z
 
+    @_on_device
     def dec_trunk(self, z_fm, g):
         B, T, _ = z_fm.shape
         z, g = self._f32(z_fm, self.device), self._f32(g, self.device)
@@ -208,6 +251,7 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_dec_trunk")
         return post
 
+    @_on_device
     def istft_synth(self, post_fm, want_bands: bool = False):
         B, F, _ = post_fm.shape
         post = self._f32(post_fm, self.device)

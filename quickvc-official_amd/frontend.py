@@ -99,9 +99,10 @@ class MelFrontend:
         if self._ws is None or self._ws.numel() < n:
             self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
         mel = torch.empty(U, self.n_mels, self.frames(N), dtype=torch.float32, device=self.device)
-        st = self.lib.qvc_wave_to_mel(self.table.data_ptr(), self.n_fft, self.hop, self.n_mels, wave.data_ptr(), mel.data_ptr(),
-                                      U, N, self._ws.data_ptr(), self._ws.numel(),
-                                      torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):     # the library keys per-device launch state on the current device
+            st = self.lib.qvc_wave_to_mel(self.table.data_ptr(), self.n_fft, self.hop, self.n_mels, wave.data_ptr(), mel.data_ptr(),
+                                          U, N, self._ws.data_ptr(), self._ws.numel(),
+                                          torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib, st, "qvc_wave_to_mel")
         return mel
 

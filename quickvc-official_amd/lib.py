@@ -76,6 +76,8 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_infer_batch_timed.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V, P(QvcLaunchRecord), I, P(I)]
         lib.qvc_enc_p.restype = ctypes.c_int
         lib.qvc_enc_p.argtypes = [cfgp, V, V, V, V, I, I, V, L, V]
+        lib.qvc_wn_stack.restype = ctypes.c_int
+        lib.qvc_wn_stack.argtypes = [cfgp, V, I, V, V, V, I, I, V, L, V]
         lib.qvc_flow_reverse.restype = ctypes.c_int
         lib.qvc_flow_reverse.argtypes = [cfgp, V, V, V, I, I, V, L, V]
         lib.qvc_dec_trunk.restype = ctypes.c_int
@@ -126,7 +128,7 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 4:
+        if lib.qvc_abi_version() != 5:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib

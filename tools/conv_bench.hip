@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(bb, 0, 1 << 20));
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (const Shape& s : shapes) {
+  if (!getenv("QVC_BENCH_PAIRS")) for (const Shape& s : shapes) {
     ConvDesc d = make_conv(s.M, s.Cin, s.k, s.dil, s.kind == 2);
     d.w_off = 0; d.b_off = align_up(d.w_bytes(), 256);
     size_t wb = d.b_off + d.b_bytes();
@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
     printf("%-14s MF%d WM%d NF%-2d chunks%d  %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d.MF, d.WM, nf, d.nchunk, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
-  {  // ---- polyphase up-samplers, conv_pre (weight-heavy, few frames)
+  if (!getenv("QVC_BENCH_PAIRS")) {  // ---- polyphase up-samplers, conv_pre (weight-heavy, few frames)
     struct U { const char* name; int Cin, Cout, T, k, s, p; int kind; };
     std::vector<U> us = {{"ups0 512>256 s5", 512, 256, 250, 16, 5, 6, 0}, {"ups1 256>128 s4", 256, 128, 1250, 16, 4, 6, 1}};
     for (const U& u : us) {
@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
       CK(hipFree(dw));
     }
   }
-  {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
+  if (!getenv("QVC_BENCH_PAIRS")) {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
     const int H = 192, T = 250, L = 16;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
     wn_layout(din, 2); wn_layout(drs, 2);
@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
     printf("%-14s W%-2d NF%-2d               %8.1f us/layer  %7.1f TF  (%.1f%% of 2.5PF)\n", "wn layer x16", din.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
-  {  // ---- whole-stack WaveNet launches: 4 layers per launch, 8 distinct weight sets (cold weights)
+  if (!getenv("QVC_BENCH_PAIRS")) {  // ---- whole-stack WaveNet launches: 4 layers per launch, 8 distinct weight sets (cold weights)
     const int H = 192, T = 250, L = 4, SETS = 8;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
     wn_layout(din, 2); wn_layout(drs, 2);
@@ -157,36 +157,81 @@ int main(int argc, char** argv) {
     printf("%-14s W%-2d L4                 %8.1f us/layer  %7.1f TF\n", "wn stack", din.WM, us, flops / us * 1e-6);
     CK(hipFree(dw));
   }
-  // ---- fused ResBlock pairs
-  struct PShape { const char* name; int C, T, k, dil; int force_mf, force_wm; };
-  std::vector<PShape> pshapes = {{"pair s2 k3 d1", 128, 5000, 3, 1}, {"pair s2 k7 d3", 128, 5000, 7, 3}, {"pair s2 k11 d5", 128, 5000, 11, 5},
-                                 {"s2 k3 MF2WM4", 128, 5000, 3, 1, 2, 4}, {"s2 k7 MF2WM4", 128, 5000, 7, 3, 2, 4}, {"s2 k11 MF2WM4", 128, 5000, 11, 5, 2, 4},
-                                 {"pair s1 k3 d1", 256, 1250, 3, 1}, {"pair s1 k7 d3", 256, 1250, 7, 3}, {"pair s1 k11 d5", 256, 1250, 11, 5}};
-  for (const PShape& s : pshapes) {
-    ConvDesc d1 = make_conv(s.C, s.C, s.k, s.dil), d2 = make_conv(s.C, s.C, s.k, 1);
-    if (s.force_mf) { d1.MF = d2.MF = s.force_mf; d1.WM = d2.WM = s.force_wm; d1.nchunk = d2.nchunk = ceil_div(s.C, s.force_mf * s.force_wm * 16); }
-    d1.w_off = 0; d1.b_off = align_up(d1.w_bytes(), 256);
-    size_t wb = d1.b_off + d1.b_bytes();
-    std::vector<char> hw(wb);
-    std::vector<float> w((size_t)s.C * s.C * s.k), bias(s.C, 0.01f);
-    for (size_t i = 0; i < w.size(); ++i) w[i] = zeros ? 0.f : ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
-    pack_plain_conv(d1, w.data(), bias.data(), QVC_F16, hw.data());
-    void* dw; CK(hipMalloc(&dw, wb)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
-    PairArgs a;
-    a.x = x16; a.bs = (int64_t)s.T * s.C; a.T = s.T; a.C = s.C; a.CP = d1.CinP;
-    a.w1 = dw; a.b1 = (const float*)((char*)dw + d1.b_off); a.w2 = dw; a.b2 = a.b1;
-    a.k = s.k; a.dil = s.dil; a.KS = d1.KS(); a.nIt = d1.nIt(); a.y = y16;
-    int nf = 0;
-    for (int i = 0; i < 3; ++i) if (launch_pair(d1, d2, a, B, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch failed\n", s.name); break; }
-    CK(hipStreamSynchronize(st));
-    CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
-    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    const double us = ms * 1e3 / reps;
-    const double flops = 2.0 * 2.0 * B * s.T * (double)s.C * s.k * s.C;
-    printf("%-14s MF%d WM%d NF%-2d          %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d1.MF, d1.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
-    CK(hipFree(dw));
+  // ---- fused ResBlock pairs: one launch per chain, and pair q of the three chains (k 3 / 7 / 11) as ONE launch
+  struct Stage { const char* name; int C, T; };
+  for (const Stage& sg : {Stage{"s2", 128, 5000}, Stage{"s1", 256, 1250}}) {
+    const int ks[3] = {11, 7, 3}, dils[3] = {1, 3, 5};
+    for (int q = 0; q < 3; ++q) {
+      ConvDesc d1s[3], d2s[3]; PairArgs3 a3; a3.n = 3;
+      void* dws[3];
+      double tot_us = 0, tot_fl = 0;
+      for (int c = 0; c < 3; ++c) {
+        ConvDesc d1 = make_conv(sg.C, sg.C, ks[c], dils[q]), d2 = make_conv(sg.C, sg.C, ks[c], 1);
+        pair_layout(d1, d2);
+        d1.w_off = 0; d1.b_off = align_up(d1.w_bytes(), 256);
+        d2.w_off = 0; d2.b_off = d1.b_off;
+        size_t wb = d1.b_off + d1.b_bytes();
+        std::vector<char> hw(wb);
+        std::vector<float> w((size_t)sg.C * sg.C * ks[c]), bias(sg.C, 0.01f);
+        for (size_t i = 0; i < w.size(); ++i) w[i] = zeros ? 0.f : ((float)((i * 1103515245u >> 10) & 0x3ff) / 512.f - 1.f) * 0.05f;
+        pack_plain_conv(d1, w.data(), bias.data(), QVC_F16, hw.data());
+        CK(hipMalloc(&dws[c], wb)); CK(hipMemcpy(dws[c], hw.data(), wb, hipMemcpyHostToDevice));
+        PairArgs a;
+        // chain c reads / writes its own slice of the big buffers (as the three ResBlocks do)
+        const size_t slice = (size_t)B * sg.T * sg.C;
+        a.x = (char*)x16 + c * slice * 2; a.bs = (int64_t)sg.T * sg.C; a.T = sg.T; a.C = sg.C; a.CP = d1.CinP;
+        a.w1 = dws[c]; a.b1 = (const float*)((char*)dws[c] + d1.b_off); a.w2 = dws[c]; a.b2 = a.b1;
+        a.k = ks[c]; a.dil = dils[q]; a.KS = d1.KS(); a.nIt = d1.nIt(); a.y = (char*)y16 + c * slice * 2;
+        d1s[c] = d1; d2s[c] = d2; a3.p[c] = a;
+        int nf = 0;
+        pair_persist_mode() = 0;
+        for (int i = 0; i < 3; ++i) if (launch_pair(d1, d2, a, B, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch failed\n", sg.name); break; }
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        const double flops = 2.0 * 2.0 * B * sg.T * (double)sg.C * ks[c] * sg.C;
+        tot_us += us; tot_fl += flops;
+        if (sg.C == 128) {   // the same single chain on the persistent kernel
+          pair_persist_mode() = 2;
+          launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
+          CK(hipStreamSynchronize(st));
+          CK(hipEventRecord(e0, st));
+          for (int i = 0; i < reps; ++i) launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
+          CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          printf("     persistent, one chain                %8.1f us  %7.1f TF\n", ms * 1e3 / reps, flops / (ms * 1e3 / reps) * 1e-6);
+          pair_persist_mode() = 0;
+        }
+        printf("pair %s k%-2d d%d  MF%d WM%d NF%-2d          %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", sg.name, ks[c], dils[q], d1.MF, d1.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
+      }
+      // one launch for the three chains: one-tile-per-workgroup kernel (mode 0) vs persistent kernel (mode 2)
+      const size_t ybytes = (size_t)3 * B * sg.T * sg.C * 2;
+      std::vector<uint16_t> y0(ybytes / 2), y1(ybytes / 2);
+      double us_mode[2] = {0, 0};
+      for (int mode = 0; mode < 2; ++mode) {
+        pair_persist_mode() = mode == 0 ? 0 : 2;
+        int nf = 0;
+        CK(hipMemsetAsync(y16, 0, ybytes, st));
+        for (int i = 0; i < 3; ++i) if (launch_pair3(d1s, d2s, a3, B, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch3 failed\n", sg.name); break; }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy((mode == 0 ? y0 : y1).data(), y16, ybytes, hipMemcpyDeviceToHost));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_pair3(d1s, d2s, a3, B, QVC_F16, st, &nf);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        us_mode[mode] = ms * 1e3 / reps;
+        printf("pair3 %s d%d  %-10s NF%-3d %8.1f us  %7.1f TF\n", sg.name, dils[q], mode == 0 ? "tile/wg" : "persistent", nf, us_mode[mode], tot_fl / us_mode[mode] * 1e-6);
+      }
+      size_t ndiff = 0;
+      for (size_t i = 0; i < y0.size(); ++i) ndiff += y0[i] != y1[i];
+      printf("pair3 %s d%d  three launches %8.1f us  %7.1f TF;  persistent vs tile/wg outputs: %zu of %zu values differ%s\n", sg.name, dils[q], tot_us,
+             tot_fl / tot_us * 1e-6, ndiff, y0.size(), ndiff ? "  <-- MISMATCH" : "");
+      pair_persist_mode() = 1;
+      for (int c = 0; c < 3; ++c) CK(hipFree(dws[c]));
+    }
   }
   return 0;
 }
