@@ -35,13 +35,24 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_sha1() -> str:
+    """Hash of the kernel sources: ties a PMC traffic file to the code it was measured on (no git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "quickvc-official_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches")
@@ -54,6 +65,7 @@ def main() -> None:
     from quickvc_official_amd.engine import QvcEngine
     from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_inputs
 
+    exit_code = 0
     rank, local_rank, world = qd.env_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
@@ -128,7 +140,8 @@ def main() -> None:
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "batch=32 offline VC, 5 s 16 kHz utterances, 1xMI355X per rank (BASELINE.json configs[2])",
                    "batch_per_gpu": B, "frames": FRAMES, "samples_per_utterance": FRAMES * engine.samples_per_frame,
-                   "operands": f"{args.dtype} MFMA operands, fp32 accumulate", "hipgraph": graph is not None,
+                   "operands": {"f16": "f16 MFMA operands, fp32 accumulate", "bf16": "bf16 MFMA operands, fp32 accumulate",
+                                "bf16x": "bf16 operands in enc_p + flow (WaveNets), f16 in the generator, fp32 accumulate"}[args.dtype], "hipgraph": graph is not None,
                    "parallel_resblock_branches": args.branches,
                    "parallelism": f"utterance-sharded x{world}, no per-step collective"},
         "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
@@ -148,17 +161,27 @@ def main() -> None:
                     total_ms += r["ms"]
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_bench.sh writes
+        # profiles/r02_traffic.json with the hash of the kernel sources it was measured on).  It is reported only
+        # when that hash matches the sources of THIS run and the file names the dominant kernel; otherwise null.
+        traffic, traffic_source = None, "no PMC file for these kernel sources (run tools/profile_bench.sh)"
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                if tj.get("kernel_source_sha1") != kernel_source_sha1():
+                    traffic_source = f"stale: {os.path.basename(tpath)} was measured on other kernel sources"
+                elif dom_name in tj.get("kernels", {}):
+                    traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
+                    traffic_source = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                      f"separate passes, same kernel sources)")
+            except Exception as exc:
+                traffic_source = f"unreadable PMC file: {exc}"
         all_flops = sum(a["flops"] for a in agg.values()) / reps
         result["roofline"] = {
             "bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": traffic,
+            "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
             "launches_per_step": dom["launches"] // reps, "avg_launch_ms": dom["ms"] / dom["launches"],
             "kernel_share_of_step": dom["ms"] / total_ms,
             "whole_step": {"flops": all_flops, "tflops": all_flops / (ms_per_step * 1e-3) / 1e12,
@@ -214,9 +237,15 @@ def main() -> None:
                                 "linf": float((ref - out[:n_cpu].cpu()).abs().max()), "tolerance_db": 40.0,
                                 "checked_utterances": n_cpu}
         print(json.dumps(result))
+        par = result.get("parity")
+        if par and not (par["snr_db_min"] >= par["tolerance_db"]):
+            print(f"PARITY FAILURE: min SNR {par['snr_db_min']:.2f} dB < {par['tolerance_db']} dB", file=sys.stderr)
+            exit_code = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 5
+#define QVC_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -58,7 +58,10 @@ enum {
 /* ---- MFMA operand types -------------------------------------------------- */
 enum {
   QVC_BF16 = 0,  /* bf16 operands, fp32 accumulate (BASELINE.json configs 2-5) */
-  QVC_F16 = 1    /* fp16 operands, fp32 accumulate (same MFMA rate, 3 more mantissa bits) */
+  QVC_F16 = 1,   /* fp16 operands, fp32 accumulate (same MFMA rate, 3 more mantissa bits) */
+  QVC_BF16X = 2  /* mixed: bf16 operands in the WaveNet half (enc_p / enc_q / flow), fp16 in the generator, whose
+                    ~75 chained convs + exp() are where bf16's 8-bit mantissa costs the waveform SNR;
+                    the two halves meet at fp32 tensors (z), so no kernel mixes operand types */
 };
 
 #define QVC_MAX_UPS 4
@@ -133,6 +136,21 @@ int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev,
                     const float* unit, const float* g, const float* noise, float* out,
                     int32_t batch, int32_t frames,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- the same for a RAGGED batch: utterances of different lengths in one launch sequence ------------------
+ * The reference converts one utterance of any length per call (convert.py:58-86, models.py:625-642); a batched
+ * drop-in therefore has to take utterances of different lengths.  unit / noise are padded to max_frames
+ * ((B, C, max_frames), the padding's content is ignored), frames_dev is a DEVICE array of `batch` int32 lengths
+ * (1 < frames_dev[b] <= max_frames; not validated on the host: the call is asynchronous; values are clamped
+ * to [0, max_frames] on the device), and every conv / WaveNet layer / iSTFT frame sees utterance b end at
+ * frames_dev[b] (zero padding at ITS end, as in the reference).  out is (B, 320*max_frames): the first
+ * 320*frames_dev[b] samples of row b equal the waveform of utterance b converted alone, the rest are zeros.
+ * Same workspace as qvc_infer_batch(cfg, batch, max_frames).
+ */
+int qvc_infer_batch_ragged(const qvc_config* cfg, const void* blob_dev,
+                           const float* unit, const float* g, const float* noise, float* out,
+                           int32_t batch, int32_t max_frames, const int32_t* frames_dev,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- optional fork/join resources: lets the three independent ResBlocks of an MRF stage
  * (models.py:378-384) run as parallel branches (two auxiliary non-blocking streams + events), so a

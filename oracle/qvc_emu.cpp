@@ -88,6 +88,7 @@ struct EmuBackend {
     if (acc_store.size() < (size_t)MP * (size_t)a.Nq) acc_store.resize((size_t)MP * (size_t)a.Nq);
     acc_ = acc_store.data();
     for (int b = 0; b < B; ++b) {
+      const int Tin = ragged_len(a.rg, b, a.T_in);          // ragged batches: the conv zero-pads at the utterance's own end
       // staged input, rounded like the LDS tile: rows t in [-left, Nq - left + halo)
       const int rows = a.Nq + R_halo;
       std::vector<float> X((size_t)rows * d.CinP, 0.f);
@@ -97,13 +98,13 @@ struct EmuBackend {
           float v = 0.f; bool ok;
           if (a.x_kind == XK_F32_FM) {
             int s;
-            if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; s = ti == 0 ? 1 : ti - 1; } else { ok = ti >= 0 && ti < a.T_in; s = ti; }
+            if (a.reflect) { ok = ti >= 0 && ti <= Tin; s = ti == 0 ? 1 : ti - 1; } else { ok = ti >= 0 && ti < Tin; s = ti; }
             if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)s * a.x_ts + a.x_c0 + c], a.slope_in), dtype);
           } else if (a.x_kind == XK_OP_FM) {
-            ok = ti >= 0 && ti < a.T_in;
+            ok = ti >= 0 && ti < Tin;
             if (a.x2) {   // MRF mean taken on the fly (reflect applies as in the fp32 path)
               int s2; bool ok2;
-              if (a.reflect) { ok2 = ti >= 0 && ti <= a.T_in; s2 = ti == 0 ? 1 : ti - 1; } else { ok2 = ok; s2 = ti; }
+              if (a.reflect) { ok2 = ti >= 0 && ti <= Tin; s2 = ti == 0 ? 1 : ti - 1; } else { ok2 = ok; s2 = ti; }
               if (ok2) {
                 const size_t o = (size_t)b * a.x_bs + (size_t)s2 * a.x_ts + a.x_c0 + c;
                 auto get = [&](const void* p) { const uint16_t h = static_cast<const uint16_t*>(p)[o]; return dtype == QVC_F16 ? from_f16(h) : from_bf16(h); };
@@ -111,7 +112,7 @@ struct EmuBackend {
               }
             } else if (ok) { uint16_t h = static_cast<const uint16_t*>(a.x)[(size_t)b * a.x_bs + (size_t)ti * a.x_ts + a.x_c0 + c]; v = dtype == QVC_F16 ? from_f16(h) : from_bf16(h); if (a.slope_in != 1.f) v = round_op(lrelu(v, a.slope_in), dtype); }
           } else {
-            ok = ti >= 0 && ti < a.T_in;
+            ok = ti >= 0 && ti < Tin;
             if (ok) v = round_op(lrelu(static_cast<const float*>(a.x)[(size_t)b * a.x_bs + (size_t)c * a.x_ts + ti], a.slope_in), dtype);
           }
           X[(size_t)r * d.CinP + c] = v;
@@ -210,10 +211,11 @@ struct EmuBackend {
     const int H = a.H, HP = din.CinP, KS = din.KS(), nIt1 = din.nIt(), left = (din.taps - 1) / 2;
     std::vector<float> xr((size_t)(a.T + din.taps) * HP), acts(HP), pre(2 * H);
     for (int b = 0; b < B; ++b) {
+      const int Tb = ragged_len(a.rg, b, a.T);
       std::fill(xr.begin(), xr.end(), 0.f);
-      for (int t = 0; t < a.T; ++t)
+      for (int t = 0; t < Tb; ++t)
         for (int c = 0; c < H; ++c) xr[(size_t)(t + left) * HP + c] = round_op(a.x_in[(size_t)b * a.bs + (size_t)t * H + c], dtype);
-      for (int t = 0; t < a.T; ++t) {
+      for (int t = 0; t < Tb; ++t) {
         for (int v = 0; v < 2 * H; ++v) {
           double acc = 0;
           for (int it = 0; it < nIt1; ++it) {
@@ -252,7 +254,7 @@ struct EmuBackend {
     if (s.w_pre) {   // fused pre 1x1: x0 = W_pre * z[in slice] + b
       ConvArgs a; fill(a, *dpre);
       a.w = s.w_pre; a.bias = s.b_pre; a.x = s.z; a.x_kind = XK_F32_FM; a.x_bs = s.z_bs; a.x_ts = s.z_ts; a.x_c0 = s.pre_c0;
-      a.T_in = s.T; a.Nq = s.T; a.T_out = s.T; a.y32 = xa.data(); a.y32_bs = s.bs; a.y32_ts = s.H;
+      a.T_in = s.T; a.Nq = s.T; a.T_out = s.T; a.y32 = xa.data(); a.y32_bs = s.bs; a.y32_ts = s.H; a.rg = s.rg;
       conv(*dpre, a, B, EPI_STD, dtype);
     } else {
       std::memcpy(xa.data(), s.x0, (size_t)B * s.bs * 4);
@@ -266,13 +268,14 @@ struct EmuBackend {
       a.w_in = s.w_in[l]; a.w_rs = s.w_rs[l]; a.b_rs = s.b_rs[l];
       a.bbias = s.bbias + (size_t)l * 2 * s.H; a.bbias_bs = s.bbias_bs;
       a.taps = s.taps; a.KS = s.KS; a.nIt1 = s.nIt1; a.last = s.final_layer && l == s.layers - 1;
+      a.rg = s.rg;
       wn(din, a.last ? drs_last : drs, a, B, dtype);
     }
     if (s.x_out) std::memcpy(s.x_out, (s.layers % 2 ? xb : xa).data(), (size_t)B * s.bs * 4);
     if (s.w_post) {  // fused post 1x1: z[out slice] -= W_post * out + b
       ConvArgs a; fill(a, *dpost);
       a.w = s.w_post; a.bias = s.b_post; a.x = out; a.x_kind = XK_F32_FM; a.x_bs = s.bs; a.x_ts = s.H;
-      a.T_in = s.T; a.Nq = s.T; a.T_out = s.T;
+      a.T_in = s.T; a.Nq = s.T; a.T_out = s.T; a.rg = s.rg;
       a.res = s.z; a.res_bs = s.z_bs; a.res_ts = s.z_ts; a.res_c0 = s.post_c0; a.res_sign = s.post_sign;
       a.y32 = s.z; a.y32_bs = s.z_bs; a.y32_ts = s.z_ts; a.y32_c0 = s.post_c0;
       conv(*dpost, a, B, EPI_STD, dtype);
@@ -280,24 +283,24 @@ struct EmuBackend {
     return QVC_OK;
   }
   // fused pair = the two convs back to back with the intermediate rounded to the operand type
-  int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& p, int B, int dtype) {
+  int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& p, int B, int dtype, const Ragged& rg = Ragged()) {
     std::vector<uint16_t> xt((size_t)B * p.bs);
     auto fill = [](ConvArgs& a, const ConvDesc& d) {
       a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left; a.KS = d.KS(); a.nIt = d.nIt();
       a.nchunk = d.nchunk; a.M = d.M; a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout; };
     ConvArgs a1; fill(a1, d1);
     a1.w = p.w1; a1.bias = p.b1; a1.x = p.x; a1.x_kind = XK_OP_FM; a1.x_bs = p.bs; a1.x_ts = p.C; a1.T_in = p.T; a1.slope_in = p.slope;
-    a1.Nq = p.T; a1.T_out = p.T; a1.y16 = xt.data(); a1.y16_bs = p.bs; a1.y16_ts = p.C; a1.slope_out = p.slope;
+    a1.rg = rg; a1.Nq = p.T; a1.T_out = p.T; a1.y16 = xt.data(); a1.y16_bs = p.bs; a1.y16_ts = p.C; a1.slope_out = p.slope;
     conv(d1, a1, B, EPI_STD, dtype);
     ConvArgs a2; fill(a2, d2);
     a2.w = p.w2; a2.bias = p.b2; a2.x = xt.data(); a2.x_kind = XK_OP_FM; a2.x_bs = p.bs; a2.x_ts = p.C; a2.T_in = p.T;
-    a2.Nq = p.T; a2.T_out = p.T; a2.res16 = p.x; a2.res_bs = p.bs; a2.res_ts = p.C;
+    a2.rg = rg; a2.Nq = p.T; a2.T_out = p.T; a2.res16 = p.x; a2.res_bs = p.bs; a2.res_ts = p.C;
     a2.y16 = p.y; a2.y16_bs = p.bs; a2.y16_ts = p.C; a2.slope_out = 1.f;
     conv(d2, a2, B, EPI_STD, dtype);
     return QVC_OK;
   }
   int pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int B, int dtype) {
-    for (int i = 0; i < a.n; ++i) pair(d1[i], d2[i], a.p[i], B, dtype);
+    for (int i = 0; i < a.n; ++i) pair(d1[i], d2[i], a.p[i], B, dtype, a.rg);
     return QVC_OK;
   }
   int gemv(const GemvArgs& a) {
@@ -320,11 +323,12 @@ struct EmuBackend {
   }
   // Tail: same formulas as istft_synth_kernel, evaluated sample by sample.
   int tail(const TailArgs& a) {
-    const int F = a.F, L = 4 * (F - 1), NO = 4 * L;
+    const int Fpad = a.F, Lpad = 4 * (Fpad - 1), NOpad = 4 * Lpad;
     const double pi = 3.14159265358979323846;
-    std::vector<double> xw((size_t)4 * F * 16), y((size_t)4 * L);
     for (int b = 0; b < a.batch; ++b) {
-      const float* pb = a.post + (size_t)b * F * 72;
+      const int F = ragged_len(a.rg, b, Fpad), L = F > 0 ? 4 * (F - 1) : 0, NO = 4 * L;   // this utterance's own frame count
+      std::vector<double> xw((size_t)4 * std::max(F, 1) * 16), y((size_t)4 * std::max(L, 1));
+      const float* pb = a.post + (size_t)b * Fpad * 72;
       for (int k = 0; k < 4; ++k)
         for (int t = 0; t < F; ++t) {
           double re[9], im[9];
@@ -340,26 +344,31 @@ struct EmuBackend {
           }
         }
       for (int k = 0; k < 4; ++k)
-        for (int n = 0; n < L; ++n) {
-          double num = 0, env = 0;
-          for (int t = 0; t < F; ++t) {
-            const int m = n + 8 - 4 * t;
-            if (m < 0 || m >= 16) continue;
-            const double w = 0.5 - 0.5 * std::cos(2 * pi * m / 16);
-            num += xw[((size_t)k * F + t) * 16 + m]; env += w * w;
+        for (int n = 0; n < Lpad; ++n) {
+          double v = 0;
+          if (n < L) {
+            double num = 0, env = 0;
+            for (int t = 0; t < F; ++t) {
+              const int m = n + 8 - 4 * t;
+              if (m < 0 || m >= 16) continue;
+              const double w = 0.5 - 0.5 * std::cos(2 * pi * m / 16);
+              num += xw[((size_t)k * F + t) * 16 + m]; env += w * w;
+            }
+            v = num / env;
+            y[(size_t)k * L + n] = v;
           }
-          y[(size_t)k * L + n] = num / env;
-          if (a.y_mb) a.y_mb[((size_t)b * 4 + k) * L + n] = (float)(num / env);
+          if (a.y_mb) a.y_mb[((size_t)b * 4 + k) * Lpad + n] = (float)v;
         }
-      for (int o = 0; o < NO; ++o) {
+      for (int o = 0; o < NOpad; ++o) {
         double s = 0;
-        for (int k = 0; k < 4; ++k)
-          for (int j = 0; j < 63; ++j) {
-            const int u = o + j - 31;
-            if (u < 0 || u >= NO || (u & 3)) continue;
-            s += (double)a.fir[k * 63 + j] * y[(size_t)k * L + (u >> 2)];
-          }
-        a.out[(size_t)b * NO + o] = (float)s;
+        if (o < NO)
+          for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 63; ++j) {
+              const int u = o + j - 31;
+              if (u < 0 || u >= NO || (u & 3)) continue;
+              s += (double)a.fir[k * 63 + j] * y[(size_t)k * L + (u >> 2)];
+            }
+        a.out[(size_t)b * NOpad + o] = (float)s;
       }
     }
     return QVC_OK;
@@ -460,6 +469,23 @@ int qvc_emu_infer_batch(const qvc_config* cfg, const void* blob, const float* un
   return c.status;
 }
 
+// Same signature as qvc_infer_batch_ragged, host pointers (the lengths too), no stream.
+int qvc_emu_infer_batch_ragged(const qvc_config* cfg, const void* blob, const float* unit, const float* g, const float* noise,
+                               float* out, int32_t batch, int32_t max_frames, const int32_t* frames_host, void* workspace,
+                               int64_t workspace_bytes) {
+  Run r;
+  int st = r.prepare(cfg, batch, max_frames, workspace_bytes);
+  if (st != QVC_OK) return st;
+  Path<EmuBackend> c{r.P, static_cast<const char*>(blob), static_cast<char*>(workspace), r.W, batch, max_frames, r.be};
+  c.lens = frames_host;
+  c.cond_table(g);
+  c.enc_p(unit, noise, c.wsp<float>(r.W.z));
+  c.flow(c.wsp<float>(r.W.z));
+  c.dec_trunk(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post));
+  c.tail(c.wsp<float>(r.W.post), out, nullptr, max_frames * r.P.total_up + 1);
+  return c.status;
+}
+
 // Same signatures as qvc_enc_q / qvc_flow_forward, host pointers, no stream.
 int qvc_emu_enc_q(const qvc_config* cfg, const void* encq_blob, const float* spec, const float* g, const float* noise,
                   float* z_fm, int32_t batch, int32_t frames, void* workspace, int64_t workspace_bytes) {
@@ -492,7 +518,7 @@ int qvc_emu_speaker_embed(const qvc_config* cfg, const void* spk_blob, const flo
   const SpkWorkspace W = carve_spk_workspace(S, utterances, mel_frames);
   if (workspace_bytes < W.bytes) return QVC_ERR_SMALL_BUFFER;
   EmuBackend be;
-  return spk_path(S, cfg->operand_dtype, static_cast<const char*>(spk_blob), static_cast<char*>(workspace), W, mel, g,
+  return spk_path(S, dec_dtype(*cfg), static_cast<const char*>(spk_blob), static_cast<char*>(workspace), W, mel, g,
                   utterances, mel_frames, be);
 }
 

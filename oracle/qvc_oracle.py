@@ -376,6 +376,24 @@ def infer(sd: State, cfg: dict, unit: Tensor, mel: Tensor, noise: Tensor) -> Ten
     return infer_from_g(sd, cfg, unit, g, noise)
 
 
+# --------------------------------------------------------------------------- mel front-end
+def wave_to_spec(wave: Tensor, n_fft: int, hop: int, win: int) -> Tensor:
+    """mel_processing.py:15-58: reflect pad (n_fft-hop)/2 per side (:46), Hann STFT center=False (:50-51),
+    sqrt(re^2 + im^2 + 1e-6) (:54).  wave :: (B, T) -> (B, n_fft/2+1, frames)."""
+    pad = int((n_fft - hop) / 2)
+    x = F.pad(wave.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    window = torch.hann_window(win, dtype=wave.dtype)
+    spec = torch.stft(x, n_fft, hop_length=hop, win_length=win, window=window, center=False, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True)
+    return torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-6)
+
+
+def wave_to_mel(wave: Tensor, mel_basis: Tensor, n_fft: int, hop: int, win: int) -> Tensor:
+    """mel_processing.py:61-98: log(clamp(mel_basis @ spec, 1e-5)) (:8, :74-75).  The filter bank is an argument:
+    the reference takes it from librosa.filters.mel (:69), which is absent here -- PARITY UNPINNED for the bank."""
+    return torch.log(torch.clamp(torch.matmul(mel_basis.to(wave.dtype), wave_to_spec(wave, n_fft, hop, win)), min=1e-5))
+
+
 def snr_db(ref: Tensor, out: Tensor) -> float:
     """10 log10( sum ref^2 / sum (ref-out)^2 ) -- the parity metric of SURVEY 8d."""
     ref, out = ref.double().flatten(), out.double().flatten()

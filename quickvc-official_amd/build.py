@@ -37,6 +37,11 @@ def _run(cmd):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), res.stdout))
+    # per-kernel resource usage (registers, scratch, occupancy) is kept next to the object file:
+    # tests/test_host_side.py checks that no hot kernel spills to scratch memory
+    if "-c" in cmd and "-o" in cmd and cmd[cmd.index("-o") + 1].endswith(".o"):
+        with open(cmd[cmd.index("-o") + 1][:-2] + ".remarks.txt", "w") as f:
+            f.write(res.stdout)
     return res.stdout
 
 
@@ -49,7 +54,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or not _newer(o, [s] + hdrs):
-            jobs.append([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o])
+            jobs.append([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+                         "-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
             for out in ex.map(_run, jobs):

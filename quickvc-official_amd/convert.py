@@ -9,8 +9,10 @@ launch), ``--seed`` (noise), ``--dtype``.
 
 Corpus scale (BASELINE.json configs[3]): started under ``torch.distributed.run`` (one process per
 GPU) every rank converts its own static shard of the list (length-sorted round-robin,
-``dist.shard_indices``); nothing is exchanged between ranks -- each rank loads the checkpoint itself, so
-there is not even a start-up broadcast in this mode.
+``dist.shard_indices``, decided from the .npy headers alone: a rank never loads another rank's units or
+targets); nothing is exchanged between ranks -- each rank loads the checkpoint itself, so there is not
+even a start-up broadcast in this mode.  Utterances of different lengths share launches through the
+ragged path (``qvc_infer_batch_ragged``): batches are cut from the length-sorted shard.
 
     python -m quickvc_official_amd.convert --hpfile logs/quickvc/config.json --ptfile quickvc.pth
 """
@@ -26,32 +28,57 @@ import torch
 from .checkpoint import load_checkpoint
 from .dist import env_world, shard_indices
 from .config import get_hparams_from_file
-from .frontend import MelFrontend, load_wav, trim, wave_to_mel
+from .frontend import MelFrontend, load_wav, trim
 from .model import SynthesizerTrn
 
 
-def _load_units(src: str) -> torch.Tensor:
+def _unit_path(src: str) -> str:
     path = src if src.endswith(".npy") else os.path.splitext(src)[0] + ".npy"
     if not os.path.exists(path):
         raise FileNotFoundError(f"no unit file for {src}: HuBERT-soft is not available offline; provide {path} "
                                 "(frames, 256) fp32 as written by the reference's dataset/encode.py")
-    u = np.load(path).astype(np.float32)
+    return path
+
+
+def unit_frames(src: str) -> int:
+    """Unit-frame count of a source from the .npy HEADER only (memory-mapped: no payload is read)."""
+    u = np.load(_unit_path(src), mmap_mode="r")
     if u.ndim != 2 or u.shape[1] != 256:
-        raise ValueError(f"{path}: expected (frames, 256), got {u.shape}")
+        raise ValueError(f"{_unit_path(src)}: expected (frames, 256), got {u.shape}")
+    return int(u.shape[0])
+
+
+def _load_units(src: str) -> torch.Tensor:
+    u = np.load(_unit_path(src)).astype(np.float32)
+    if u.ndim != 2 or u.shape[1] != 256:
+        raise ValueError(f"{_unit_path(src)}: expected (frames, 256), got {u.shape}")
     return torch.from_numpy(u).t().unsqueeze(0)               # (1, 256, frames), data_utils_new_new.py:121-122
 
 
-def plan_batches(lengths, batch: int):
-    """Utterances of equal unit length share a launch (the path has no masks, so padding would change
-    the result near the end); returns lists of item indices, longest first."""
-    by_len = {}
-    for i, n in enumerate(lengths):
-        by_len.setdefault(int(n), []).append(i)
-    plan = []
-    for n in sorted(by_len, reverse=True):
-        group = by_len[n]
-        plan.extend(group[i:i + batch] for i in range(0, len(group), batch))
+def plan_batches(lengths, batch: int, max_pad: float = 0.25):
+    """Length-bucketed batches for the ragged path: items sorted by decreasing length, then cut into runs of at most
+    ``batch`` whose shortest member is at least (1 - max_pad) of the longest (padding is skipped work per tile, but
+    a batch still runs as long as its longest utterance).  Returns lists of item indices, longest first."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    plan, cur = [], []
+    for i in order:
+        if cur and (len(cur) >= batch or int(lengths[i]) < (1.0 - max_pad) * int(lengths[cur[0]])):
+            plan.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        plan.append(cur)
     return plan
+
+
+def rank_plan(items, rank: int, world: int, batch: int):
+    """This rank's work for a ``title|src|tgt`` list: (lengths of ALL sources -- headers only --, this rank's item
+    indices, its ragged batches as lists of GLOBAL item indices).  Pure host logic: nothing but .npy headers is read,
+    so every rank can plan the whole corpus while loading only its own share."""
+    lengths = [unit_frames(src) for _, src, _ in items]
+    mine = shard_indices(len(items), rank, world, lengths)
+    batches = [[mine[i] for i in idxs] for idxs in plan_batches([lengths[i] for i in mine], batch)]
+    return lengths, mine, batches
 
 
 def main(argv=None) -> None:
@@ -63,14 +90,15 @@ def main(argv=None) -> None:
     p.add_argument("--use_timestamp", default=False, action="store_true")
     p.add_argument("--batch", type=int, default=32)
     p.add_argument("--seed", type=int, default=None)
-    p.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    p.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x"])
     args = p.parse_args(argv)
 
     from scipy.io.wavfile import write
     os.makedirs(args.outdir, exist_ok=True)
     hps = get_hparams_from_file(args.hpfile)
     rank, local_rank, world = env_world()
-    torch.cuda.set_device(local_rank)
+    # QVC_CLI_REHEARSAL=1 (never set in production): every rank on cuda:0, to rehearse the sharded run on a one-GPU box
+    torch.cuda.set_device(0 if os.environ.get("QVC_CLI_REHEARSAL") == "1" else local_rank)
     print("Loading model...")
     net_g = SynthesizerTrn(hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
                            **hps.model, operand_dtype=args.dtype).cuda().eval()
@@ -85,32 +113,27 @@ def main(argv=None) -> None:
                 title, src, tgt = raw.strip().split("|")
                 items.append((title, src, tgt))
     if args.seed is not None:
-        torch.manual_seed(args.seed)
+        torch.manual_seed(args.seed + rank)
 
     print("Synthesizing...")
     d = hps.data
     with torch.no_grad():
-        # speaker embeddings once per distinct target (the reference recomputes them per line)
-        g_cache = {}
-        prepared = []
-        # mel front-end on the GPU (qvc_wave_to_mel) when the config has win == n_fft, else the torch restatement
+        # Shard FIRST: the split only needs every source's length, read from the .npy headers; units are loaded
+        # and targets embedded for this rank's own items only (O(corpus / world) work and memory per rank).
+        _lengths, _mine, batches = rank_plan(items, rank, world, args.batch)
+        # mel front-end on the GPU (qvc_wave_to_mel; raises for configs it does not cover -- there is no CPU path)
         front = MelFrontend(d.filter_length, d.n_mel_channels, d.sampling_rate, d.hop_length, d.win_length,
-                            d.mel_fmin, d.mel_fmax) if d.win_length == d.filter_length and d.hop_length % 16 == 0 else None
-        for title, src, tgt in items:
-            if tgt not in g_cache:
-                wav = torch.from_numpy(trim(load_wav(tgt, d.sampling_rate), top_db=20)).unsqueeze(0).cuda()
-                mel = front(wav) if front is not None else wave_to_mel(wav, d.filter_length, d.n_mel_channels, d.sampling_rate,
-                                                                       d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
-                g_cache[tgt] = net_g.speaker_embed(mel)                 # (1, 80, F') -> (1, gin), HIP LSTM
-            prepared.append((title, _load_units(src), g_cache[tgt]))
-        # this rank's shard of the list, then equal-length utterances share a launch
-        mine = shard_indices(len(prepared), rank, world, [p[1].shape[-1] for p in prepared])
-        prepared = [prepared[i] for i in mine]
-        for idxs in plan_batches([p[1].shape[-1] for p in prepared], args.batch):
-            chunk = [prepared[i] for i in idxs]
-            unit = torch.cat([u for _, u, _ in chunk], 0).cuda()
-            g = torch.cat([gg for _, _, gg in chunk], 0)
-            audio = net_g.infer_batch(unit, g)
+                            d.mel_fmin, d.mel_fmax)
+        g_cache = {}                                # speaker embeddings once per distinct target (the reference recomputes per line)
+        for idxs in batches:
+            chunk = [items[i] for i in idxs]
+            for _, _, tgt in chunk:
+                if tgt not in g_cache:
+                    wav = torch.from_numpy(trim(load_wav(tgt, d.sampling_rate), top_db=20)).unsqueeze(0).cuda()
+                    g_cache[tgt] = net_g.speaker_embed(front(wav))          # (1, 80, F') -> (1, gin), HIP mel + HIP LSTM
+            units = [_load_units(src) for _, src, _ in chunk]
+            g = torch.cat([g_cache[tgt] for _, _, tgt in chunk], 0)
+            audio = net_g.infer_ragged(units, g)                              # every utterance at its own length
             for (title, _, _), a in zip(chunk, audio):
                 name = f"{time.strftime('%m-%d_%H-%M', time.localtime())}_{title}.wav" if args.use_timestamp else f"{title}.wav"
                 write(os.path.join(args.outdir, name), d.sampling_rate, a[0].float().cpu().numpy())

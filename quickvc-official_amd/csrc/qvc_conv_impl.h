@@ -158,12 +158,12 @@ __device__ __forceinline__ void gemm_loop_primed(f32x4 (&acc)[MF][NF], typename 
     for (int u = 0; u < RING; ++u) {
       const int it = it0 + u;
       if (it < nIt) {                                           // wave-uniform
-        if (it + kPF < nIt) {
+        if (it + kPF < nIt && !QVC_ABL(5)) {
 #pragma unroll
           for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pf * MF + m) * 64];
           ++pf;
         }
-        if (it + 1 < nIt) read_b(bf[(u + 1) & 1]);
+        if (it + 1 < nIt && !QVC_ABL(6)) read_b(bf[(u + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);                      // loads stay above this step's MFMAs
 #pragma unroll
         for (int n = 0; n < NF; ++n)
@@ -229,9 +229,11 @@ __device__ __forceinline__ void gemm_loop_il(f32x4 (&acc)[MF][NF], const typenam
       if (it0 + u < nIt) {                                          // wave-uniform
         const int pfi = pf < last ? pf : last;
         ++pf;
+        if (!QVC_ABL(5)) {
 #pragma unroll
-        for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pfi * MF + m) * 64];
-        read_b(bf[(u + 1) & 1]);
+          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pfi * MF + m) * 64];
+        }
+        if (!QVC_ABL(6)) read_b(bf[(u + 1) & 1]);
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
@@ -268,6 +270,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int cpr = a.CinP >> 3;                                  // 16-byte chunks per row
   const Swz sm = swz_mode(cpr);
   const int t_base = q0 - a.left;                               // input frame of tile row 0
+  const int Tin = ragged_len(a.rg, b, a.T_in);                  // this utterance's input length (ragged batches)
+  if (a.rg.lens && t_base >= Tin + a.reflect) return;           // tile past the end of the utterance: nothing anybody reads
 
   // ------------------------------------------------------------------ stage the activation tile
   // Loads are issued in batches per thread before anything is converted or stored, so that one
@@ -286,8 +290,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
         bool ok; int src;
-        if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; src = ti == 0 ? 1 : ti - 1; }
-        else { ok = ti >= 0 && ti < a.T_in; src = ti; }
+        if (a.reflect) { ok = ti >= 0 && ti <= Tin; src = ti == 0 ? 1 : ti - 1; }
+        else { ok = ti >= 0 && ti < Tin; src = ti; }
         ok = ok && idx < total && (c8 * 8 < a.Cin);
         v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
         if (ok) {
@@ -324,8 +328,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
         bool ok; int src;
-        if (a.reflect) { ok = ti >= 0 && ti <= a.T_in; src = ti == 0 ? 1 : ti - 1; }
-        else { ok = ti >= 0 && ti < a.T_in; src = ti; }
+        if (a.reflect) { ok = ti >= 0 && ti <= Tin; src = ti == 0 ? 1 : ti - 1; }
+        else { ok = ti >= 0 && ti < Tin; src = ti; }
         ok = ok && idx < total && (c8 * 8 < a.Cin);
         v1[u] = make_uint4(0u, 0u, 0u, 0u); v2[u] = v1[u]; v3[u] = v1[u];
         if (ok) {
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int idx = base + u * 256;
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
-        const bool ok = idx < total && ti >= 0 && ti < a.T_in && (c8 * 8 < a.Cin);
+        const bool ok = idx < total && ti >= 0 && ti < Tin && (c8 * 8 < a.Cin);
         v[u] = make_uint4(0u, 0u, 0u, 0u);
         if (ok) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.x_ts + c8 * 8);
         dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int c = idx / R, r = idx - c * R;
         const int ti = t_base + r;
         v[u] = 0.f;
-        if (idx < total && c < a.Cin && ti >= 0 && ti < a.T_in) v[u] = xb[(size_t)c * a.x_ts + ti];
+        if (idx < total && c < a.Cin && ti >= 0 && ti < Tin) v[u] = xb[(size_t)c * a.x_ts + ti];
         dst[u] = idx < total ? r * rowbytes + (((c >> 3) ^ swz(r, sm)) << 4) + (c & 7) * 2 : -1;
       }
 #pragma unroll
@@ -542,6 +546,8 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   const Swz sm = swz_mode(cpr);
   const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
   const int cb = wm * MF * 16 + lq * 4 * MF;   // first of this lane's 4*MF consecutive channels
+  const int Tb = ragged_len(A.rg, b, a.T);     // this utterance's length: both convs zero-pad at ITS end
+  if (q0 >= Tb) return;                        // tile past the end of the utterance (ragged batches)
 
   if (!QVC_ABL(0)) {   // ---- stage lrelu(x): every load of the tile is in flight before the first conversion
     // (no accumulator is live yet, so the registers are free: one memory round trip per tile instead of two)
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         const int idx = base + u * NTHR;
         const int ti = t_base + r;
         v[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (idx < total && ti >= 0 && ti < a.T && c8 * 8 < a.C) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
+        if (idx < total && ti >= 0 && ti < Tb && c8 * 8 < a.C) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
         c8 += cstep; r += rstep;
         if (c8 >= cpr) { c8 -= cpr; ++r; }
       }
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
     for (int n = 0; n < NF1; ++n) {
       const int jr = wn * (NF1 * 16) + n * 16 + lrow;            // intermediate row <-> frame q0 - h2 + jr
       const int f = q0 - h2 + jr;
-      const bool inside = f >= 0 && f < a.T;                     // conv2 zero-pads outside [0, T)
+      const bool inside = f >= 0 && f < Tb;                      // conv2 zero-pads outside [0, T)
       char* rowp = smem + jr * rowbytes;
       const int sw = swz(jr, sm);
       if constexpr (kWide) {
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
-          const bool ok = v < a.C && q < a.T && !QVC_ABL(3);
+          const bool ok = v < a.C && q < Tb && !QVC_ABL(3);
           rr[m / 2][n] = *reinterpret_cast<const uint4*>(xres + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0));
         }
       }
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
-          if (q >= a.T) continue;
+          if (q >= Tb) continue;
           frag r8; __builtin_memcpy(&r8, &rr[m / 2][n], 16);
           frag h;
           h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
-          const bool ok = v < a.C && q < a.T && !QVC_ABL(3);
+          const bool ok = v < a.C && q < Tb && !QVC_ABL(3);
           rr[m][n] = *reinterpret_cast<const quad*>(xres + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0));
         }
       }
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
-          if (q >= a.T) continue;
+          if (q >= Tb) continue;
           const quad r4 = rr[m][n];
           quad h;
           h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r4[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r4[1]);
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lq = lane >> 4;
-  const int CP = RB ? RB / 2 : A.p[0].CP, C = A.p[0].C, T_ = A.p[0].T;
+  const int CP = RB ? RB / 2 : A.p[0].CP, C = A.p[0].C, Tpad = A.p[0].T;
   const int rowbytes = CP * 2;
   const int cpr = CP >> 3;
   const Swz sm = swz_mode(cpr);
@@ -771,6 +777,7 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
   auto issue_loads = [&](const PairArgs& a, int b, int q0) {
     const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
     const int t_base = q0 - h2 - h1;
+    const int T_ = Tpad;                               // clamped addresses only need to stay inside the buffer
     const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
     const int cmax = (C >> 3) - 1;
     int r = r_0, c8 = c_0;
@@ -783,7 +790,8 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
       if (c8 >= cpr) { c8 -= cpr; ++r; }
     }
   };
-  auto write_tile = [&](const PairArgs& a, int q0) {
+  auto write_tile = [&](const PairArgs& a, int b, int q0) {
+    const int T_ = ragged_len(A.rg, b, Tpad);          // rows past the utterance's end are zeros (ragged batches)
     const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
     const int total = (N1P + 2 * h1) * cpr;
     const int t_base = q0 - h2 - h1;
@@ -810,10 +818,11 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
   PairArgs a; int b, q0;
   decode(it, a, b, q0);
   issue_loads(a, b, q0);
-  write_tile(a, q0);
+  write_tile(a, b, q0);
   lds_barrier();
 
   for (;;) {
+    const int T_ = ragged_len(A.rg, b, Tpad);
     const int nxt = it + gridDim.x;
     const bool has_next = nxt < items;                 // wave-uniform (scalar)
     {   // ---- GEMM1 over N1P frames, then bias + lrelu -> intermediate tile (in place of the input tile)
@@ -927,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
     lds_barrier();                                     // every wave is done with the intermediate and the residual rows
     it = nxt;
     decode(it, a, b, q0);
-    write_tile(a, q0);
+    write_tile(a, b, q0);
     lds_barrier();
   }
 }
@@ -959,6 +968,8 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
   const Swz sm = swz_mode(cpr);
   char* acts = smem + R * rowbytes;                              // second tile: NT rows of gated activations
   const float* xb = a.x_in + (size_t)b * a.bs;
+  const int Tb = ragged_len(a.rg, b, a.T);
+  if (q0 >= Tb) return;
 
   if (!QVC_ABL(0)) {   // ---- stage x (fp32 -> operand type), rows [q0-left, q0-left+R)
     const int total = R * cpr;
@@ -971,7 +982,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
         const int idx = base + u * NTH;
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = q0 - left + r;
-        const bool ok = idx < total && ti >= 0 && ti < a.T && (c8 * 8 < a.H);
+        const bool ok = idx < total && ti >= 0 && ti < Tb && (c8 * 8 < a.H);
         v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
         if (ok) {
           const float4* p = reinterpret_cast<const float4*>(xb + (size_t)ti * a.H + c8 * 8);
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const int q = q0 + n * 16 + lrow;
-        const bool ok = ch0 < a.H && q < a.T && !QVC_ABL(3);
+        const bool ok = ch0 < a.H && q < Tb && !QVC_ABL(3);
         const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
         xin[f][n] = make_float4(0.f, 0.f, 0.f, 0.f); oin[f][n] = xin[f][n];
         if (ok) {
@@ -1061,7 +1072,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const int q = q0 + n * 16 + lrow;
-        if (q >= a.T) continue;
+        if (q >= Tb) continue;
         const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
         float4 sk;
         if constexpr (!LAST) {
@@ -1100,6 +1111,8 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * kWnOutFrames;
+  const int Tb = ragged_len(a.rg, b, a.T);    // this utterance's length: x is zero outside [0, Tb) at every layer
+  if (q0 >= Tb) return;
   const int left = (a.taps - 1) / 2;
   const int halo = left * a.layers;
   const int w0 = q0 - halo;                   // first frame of the window; column j <-> frame w0 + j
@@ -1124,7 +1137,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
     for (int idx = tid; idx < NB * pcpr; idx += NTH) {
       const int r = idx / pcpr, c8 = idx - r * pcpr;
       const int q = w0 + r;
-      if (q >= 0 && q < a.T && c8 * 8 < a.pre_cin) {
+      if (q >= 0 && q < Tb && c8 * 8 < a.pre_cin) {
         const float4* p = reinterpret_cast<const float4*>(zb + (size_t)q * a.z_ts + c8 * 8);
         const float4 v0 = p[0], v1 = p[1];
         frag h;
@@ -1149,7 +1162,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const int q = w0 + n * 16 + lrow;
-        const bool in = ch0 < a.H && q >= 0 && q < a.T;
+        const bool in = ch0 < a.H && q >= 0 && q < Tb;
         xr[f][n] = in ? f32x4{pacc[f][n][0] + bp.x, pacc[f][n][1] + bp.y, pacc[f][n][2] + bp.z, pacc[f][n][3] + bp.w}
                       : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -1163,12 +1176,12 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       const int q = w0 + n * 16 + lrow;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!a.w_pre) {
-        if (ch0 < a.H && q >= 0 && q < a.T) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
+        if (ch0 < a.H && q >= 0 && q < Tb) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
         xr[f][n] = f32x4{v.x, v.y, v.z, v.w};
       }
       if (n >= OLO && n < OLO + ON) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.accum && ch0 < a.H && q >= q0 && q < q0 + kWnOutFrames && q < a.T)      // continue a previous launch's skip sum
+        if (a.accum && ch0 < a.H && q >= q0 && q < q0 + kWnOutFrames && q < Tb)      // continue a previous launch's skip sum
           o = *reinterpret_cast<const float4*>(a.out + (size_t)b * a.bs + (size_t)q * a.H + ch0);
         outr[f][n - OLO] = f32x4{o.x, o.y, o.z, o.w};
       }
@@ -1248,7 +1261,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
           for (int n = 0; n < NF; ++n) {
             const int q = w0 + n * 16 + lrow;
-            const bool in = q >= 0 && q < a.T;                  // the convs zero-pad x outside the utterance
+            const bool in = q >= 0 && q < Tb;                  // the convs zero-pad x outside the utterance
             xr[f][n][0] = in ? xr[f][n][0] + acc[f][n][0] + b0.x : 0.f;
             xr[f][n][1] = in ? xr[f][n][1] + acc[f][n][1] + b0.y : 0.f;
             xr[f][n][2] = in ? xr[f][n][2] + acc[f][n][2] + b0.z : 0.f;
@@ -1321,13 +1334,13 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         for (int n = 0; n < ON; ++n) {
           const int q = w0 + (OLO + n) * 16 + lrow;
           zin[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (q >= q0 && q < q0 + kWnOutFrames && q < a.T)
+          if (q >= q0 && q < q0 + kWnOutFrames && q < Tb)
             zin[n] = *reinterpret_cast<const float4*>(a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v);
         }
 #pragma unroll
         for (int n = 0; n < ON; ++n) {
           const int q = w0 + (OLO + n) * 16 + lrow;
-          if (q >= q0 && q < q0 + kWnOutFrames && q < a.T) {
+          if (q >= q0 && q < q0 + kWnOutFrames && q < Tb) {
             float* p = a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v;
             float4 zz = zin[n];
             zz.x += a.post_sign * (qacc[m][n][0] + bq.x); zz.y += a.post_sign * (qacc[m][n][1] + bq.y);
@@ -1347,7 +1360,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
     for (int n = OLO; n < OLO + ON; ++n) {
       const int q = w0 + n * 16 + lrow;
-      if (q >= q0 && q < q0 + kWnOutFrames && q < a.T) {
+      if (q >= q0 && q < q0 + kWnOutFrames && q < Tb) {
         const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
         *reinterpret_cast<float4*>(a.out + off) =
             make_float4(outr[f][n - OLO][0], outr[f][n - OLO][1], outr[f][n - OLO][2], outr[f][n - OLO][3]);

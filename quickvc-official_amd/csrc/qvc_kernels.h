@@ -11,6 +11,28 @@ enum XKind : int32_t {
   XK_F32_CM = 2    // fp32, channel-major (B, C, T) -- the reference's external layout
 };
 
+// Ragged batches (utterances of different lengths padded to one shape): utterance b has lens[b] unit frames, and a
+// launch that works at `mul` frames per unit frame (+ add) treats it as  min(T, lens[b] * mul + add)  frames long.
+// Every conv zero-pads at the end of ITS sequence (not of the padded buffer), so the staging code masks rows by
+// this length; rows past it are never read unmasked, which is why nothing has to be zeroed between launches.
+// lens == nullptr: all utterances are T frames long.  lens lives wherever the launch's other pointers live.
+struct Ragged {
+  const int32_t* lens = nullptr;
+  int32_t mul = 1, add = 0;
+};
+#if defined(__HIPCC__)
+#define QVC_HD __host__ __device__ __forceinline__
+#else
+#define QVC_HD inline
+#endif
+// (by value and always inlined: a reference to a member of the by-value kernel arguments would make the compiler
+//  copy the whole argument struct to scratch memory -- measured: 296 B of scratch and half the occupancy)
+QVC_HD int ragged_len(const Ragged r, int b, int T) {
+  if (!r.lens) return T;
+  const int n = r.lens[b] * r.mul + r.add;
+  return n < 0 ? 0 : (n < T ? n : T);
+}
+
 // Arguments of one implicit-GEMM conv launch.  All strides in elements.
 struct ConvArgs {
   // ---- input
@@ -41,6 +63,7 @@ struct ConvArgs {
   // res/skip split (WN 1x1, modules.py:104-112): rows >= split go to y32b[.. v-split] += val
   float* y32b = nullptr; int32_t split = 0;
   int32_t gau_H = 0;       // EPI_GAU: hidden size (rows are [tanh | sigmoid])
+  Ragged rg;               // per-utterance INPUT length (in T_in units); see Ragged
 };
 
 // Arguments of one fused ResBlock1 pair (modules.py:148-153):  y = x + conv2(lrelu(conv1(lrelu(x)))).
@@ -61,6 +84,7 @@ struct PairArgs {
 struct PairArgs3 {
   PairArgs p[3];
   int32_t n = 1;
+  Ragged rg;               // per-utterance length (in T units), shared by the chains
 };
 
 // One fused WaveNet layer (modules.py:87-112): k-tap conv h->2h + conditioning + tanh*sigmoid gate, then the
@@ -73,6 +97,7 @@ struct WnArgs {
   const void* w_in = nullptr; const void* w_rs = nullptr; const float* b_rs = nullptr;
   const float* bbias = nullptr; int64_t bbias_bs = 0;
   int32_t taps = 1, KS = 1, nIt1 = 1, last = 0;
+  Ragged rg;
 };
 
 // A whole WaveNet stack (modules.py:69-114) in one launch: every workgroup carries a 32-frame output tile
@@ -98,6 +123,7 @@ struct WnStackArgs {
   const void* w_post = nullptr; const float* b_post = nullptr; int32_t post_m = 0, post_c0 = 0, post_mf = 0;
   float* z = nullptr; int64_t z_bs = 0; int32_t z_ts = 0;
   float post_sign = -1.f;   // -1: reverse flow, x1 - m (modules.py:217); +1: forward flow, m + x1
+  Ragged rg;
 };
 
 struct GemvArgs {
@@ -116,6 +142,7 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
   float* out;         // [B][subbands*hop*(F-1)]
   float* y_mb;        // optional [B][subbands][hop*(F-1)]
   int32_t batch, F;
+  Ragged rg;          // per-utterance frame count min(F, lens*mul + add); samples past it are written as zeros
 };
 
 // One LSTM layer's recurrence over all partials (models.py:510,516): gates = xp[t] + W_hh h[t-1], PyTorch gate

@@ -102,7 +102,8 @@ struct Packer {
     return b;
   }
 
-  uint16_t cvt(float f) const { return cfg.operand_dtype == QVC_F16 ? to_f16(f) : to_bf16(f); }
+  int cur_dtype = -1;     // operand type of the section being packed (-1: the config's WaveNet-half type)
+  uint16_t cvt(float f) const { return (cur_dtype < 0 ? wn_dtype(cfg) : cur_dtype) == QVC_F16 ? to_f16(f) : to_bf16(f); }
 
   // wv(v, tap, ci): virtual weight; bv(v): bias (ignored when the descriptor carries no bias slot).
   void pack(const ConvDesc& d, const std::function<float(int, int, int)>& wv, const std::function<float(int)>& bv) {
@@ -176,6 +177,7 @@ extern "C" int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors
     pk.tensors[tensors[i].name] = &tensors[i];
   }
   const int H = cfg->hidden_channels, C = cfg->inter_channels, half = C / 2, gin = cfg->gin_channels;
+  pk.cur_dtype = wn_dtype(*cfg);         // ---- WaveNet half
 
   // ---- enc_p (models.py:71-73,583)
   pk.pack_conv1d(P.enc_pre, "enc_p.pre");
@@ -225,6 +227,7 @@ extern "C" int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors
   }
 
   // ---- decoder (models.py:327-357)
+  pk.cur_dtype = dec_dtype(*cfg);        // ---- generator half
   if (pk.status == QVC_OK) {
     auto w = pk.weight("dec.conv_pre", cfg->upsample_initial_channel, C, 7);
     if (pk.status == QVC_OK)
@@ -336,6 +339,7 @@ extern "C" int qvc_spk_pack_weights(const qvc_config* cfg, const qvc_tensor* ten
   if (blob_bytes < S.blob_bytes) return QVC_ERR_SMALL_BUFFER;
   std::memset(blob_host, 0, (size_t)S.blob_bytes);
   Packer pk{*cfg, {}, static_cast<char*>(blob_host)};
+  pk.cur_dtype = dec_dtype(*cfg);         // the speaker encoder runs in the generator half's operand type
   for (int i = 0; i < n_tensors; ++i) {
     if (!tensors[i].name || !tensors[i].data || tensors[i].ndim < 0 || tensors[i].ndim > 4) return QVC_ERR_BAD_ARG;
     pk.tensors[tensors[i].name] = &tensors[i];

@@ -29,9 +29,13 @@ struct Path {
   int B, T;
   Backend& be;
   int status = QVC_OK;
+  // ragged batch: per-utterance unit-frame counts (nullptr: every utterance is T frames long); see Ragged
+  const int32_t* lens = nullptr;
+  Ragged rg(int mul, int add = 0) const { Ragged r; r.lens = lens; r.mul = mul; r.add = add; return r; }
 
   template <typename U> U* wsp(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
-  int dtype() const { return P.cfg.operand_dtype; }
+  int dtype_wn() const { return wn_dtype(P.cfg); }     // enc_p / enc_q / flow
+  int dtype_dec() const { return dec_dtype(P.cfg); }   // generator
 
   ConvArgs args(const ConvDesc& d, const char* wb = nullptr) const {
     ConvArgs a;
@@ -43,11 +47,11 @@ struct Path {
     a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout;
     return a;
   }
-  void conv(const ConvDesc& d, const ConvArgs& a, int epi = EPI_STD) {
+  void conv(const ConvDesc& d, const ConvArgs& a, int dt, int epi = EPI_STD) {
     if (status != QVC_OK) return;
     const ConvDesc g = generic_layout(d);
     ConvArgs ga = a; ga.nchunk = g.nchunk;
-    status = be.conv(g, ga, B, epi, dtype());
+    status = be.conv(g, ga, B, epi, dt);
   }
   void zero(int64_t off, int64_t bytes) {
     if (status != QVC_OK) return;
@@ -85,8 +89,9 @@ struct Path {
         a.layers = chunk; a.taps = wn.in_conv[0].taps; a.KS = wn.in_conv[0].KS(); a.nIt1 = wn.in_conv[0].nIt();
         a.final_layer = l0 + chunk == wn.layers ? 1 : 0;
         a.accum = l0 > 0 ? 1 : 0;
+        a.rg = rg(1);
         a.x_out = a.final_layer ? nullptr : wsp<float>(part % 2 == 0 ? W.xw2 : W.xw);
-        if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype(), nullptr, nullptr);
+        if (status == QVC_OK) status = be.wn_stack(wn.in_conv[0], wn.rs_conv[0], wn.rs_conv[wn.layers - 1], a, B, dtype_wn(), nullptr, nullptr);
       }
       return;
     }
@@ -103,7 +108,8 @@ struct Path {
       a.b_rs = reinterpret_cast<const float*>(wb + drs.b_off);
       a.bbias = bb + (int64_t)l * 2 * H; a.bbias_bs = bb_bs;
       a.taps = din.taps; a.KS = din.KS(); a.nIt1 = din.nIt(); a.last = l == wn.layers - 1 ? 1 : 0;
-      if (status == QVC_OK) status = be.wn(din, drs, a, B, dtype());
+      a.rg = rg(1);
+      if (status == QVC_OK) status = be.wn(din, drs, a, B, dtype_wn());
     }
   }
 
@@ -114,17 +120,17 @@ struct Path {
     {
       ConvArgs a = args(P.enc_pre);
       a.x = unit; a.x_kind = XK_F32_CM; a.x_bs = (int64_t)c.unit_channels * T; a.x_ts = T; a.T_in = T;
-      a.Nq = T; a.T_out = T;
+      a.Nq = T; a.T_out = T; a.rg = rg(1);
       a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
-      conv(P.enc_pre, a);
+      conv(P.enc_pre, a, dtype_wn());
     }
     wn(P.enc_wn, reinterpret_cast<const float*>(blob + P.enc_wn.inbias_off), 0);
     {
       ConvArgs a = args(P.enc_proj);
       a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
-      a.Nq = T; a.T_out = T;
+      a.Nq = T; a.T_out = T; a.rg = rg(1);
       a.y32 = wsp<float>(W.stats); a.y32_bs = (int64_t)T * 2 * C; a.y32_ts = 2 * C;
-      conv(P.enc_proj, a);
+      conv(P.enc_proj, a, dtype_wn());
     }
     if (status != QVC_OK) return;
     SampleArgs sa{wsp<float>(W.stats), noise, z_out, B, T, C};
@@ -142,17 +148,17 @@ struct Path {
     {
       ConvArgs a = args(Q.pre, qblob);
       a.x = spec; a.x_kind = XK_F32_CM; a.x_bs = (int64_t)Q.spec_channels * T; a.x_ts = T; a.T_in = T;
-      a.Nq = T; a.T_out = T;
+      a.Nq = T; a.T_out = T; a.rg = rg(1);
       a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
-      conv(Q.pre, a);
+      conv(Q.pre, a, dtype_wn());
     }
     wn(Q.wn, wsp<float>(W.bb), Q.cond_rows, qblob);
     {
       ConvArgs a = args(Q.proj, qblob);
       a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
-      a.Nq = T; a.T_out = T;
+      a.Nq = T; a.T_out = T; a.rg = rg(1);
       a.y32 = wsp<float>(W.stats); a.y32_bs = (int64_t)T * 2 * C; a.y32_ts = 2 * C;
-      conv(Q.proj, a);
+      conv(Q.proj, a, dtype_wn());
     }
     if (status != QVC_OK) return;
     SampleArgs sa{wsp<float>(W.stats), noise, z_out, B, T, C};
@@ -189,25 +195,26 @@ struct Path {
         a.w_post = blob + f.post.w_off; a.b_post = reinterpret_cast<const float*>(blob + f.post.b_off);
         a.post_m = f.post.M; a.post_c0 = f.out_c0; a.post_mf = f.post.MF;
         a.z = z; a.z_bs = (int64_t)T * C; a.z_ts = C; a.post_sign = sign;
+        a.rg = rg(1);
         if (status == QVC_OK)
-          status = be.wn_stack(din, f.wn.rs_conv[0], f.wn.rs_conv[f.wn.layers - 1], a, B, dtype(), &f.pre, &f.post);
+          status = be.wn_stack(din, f.wn.rs_conv[0], f.wn.rs_conv[f.wn.layers - 1], a, B, dtype_wn(), &f.pre, &f.post);
         return;
       }
       {
         ConvArgs a = args(f.pre);
         a.x = z; a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * C; a.x_ts = C; a.x_c0 = f.in_c0; a.T_in = T;
-        a.Nq = T; a.T_out = T;
+        a.Nq = T; a.T_out = T; a.rg = rg(1);
         a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
-        conv(f.pre, a);
+        conv(f.pre, a, dtype_wn());
       }
       wn(f.wn, bb + f.cond_row0, P.cond_rows);
       {   // x1 <- x1 -/+ post(h)   (modules.py:214-217)
         ConvArgs a = args(f.post);
         a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
-        a.Nq = T; a.T_out = T;
+        a.Nq = T; a.T_out = T; a.rg = rg(1);
         a.res = z; a.res_bs = (int64_t)T * C; a.res_ts = C; a.res_c0 = f.out_c0; a.res_sign = sign;
         a.y32 = z; a.y32_bs = (int64_t)T * C; a.y32_ts = C; a.y32_c0 = f.out_c0;
-        conv(f.post, a);
+        conv(f.post, a, dtype_wn());
       }
     }
   }
@@ -228,12 +235,13 @@ struct Path {
     {   // conv_pre(k7) + cond(g), then the first stage's leaky ReLU fused into the store
       ConvArgs a = args(P.conv_pre);
       a.x = z; a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * C; a.x_ts = C; a.T_in = T;
-      a.Nq = T; a.T_out = T;
+      a.Nq = T; a.T_out = T; a.rg = rg(1);
       a.bbias = wsp<float>(W.bb) + P.dec_cond_row0; a.bbias_bs = P.cond_rows;
       a.y16 = wsp<void>(W.c0); a.y16_bs = (int64_t)T * C0; a.y16_ts = C0; a.slope_out = 0.1f;
-      conv(P.conv_pre, a);
+      conv(P.conv_pre, a, dtype_dec());
     }
     int t_in = T, ch_in = C0;
+    int rate = 1;                                    // frames per unit frame at the current stage's INPUT
     for (size_t i = 0; i < P.stages.size(); ++i) {
       const StagePlan& st = P.stages[i];
       const int s = st.up.up_s, p = st.up.up_p, k = c.upsample_kernel_sizes[i];
@@ -245,10 +253,11 @@ struct Path {
         if (i == 0) { a.x = wsp<void>(W.c0); a.x_kind = XK_OP_FM; }
         else { mean_input(a, i - 1); a.slope_in = 0.1f; }
         a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in; a.T_in = t_in;
-        a.Nq = (t_out - 1 + p) / s + 1; a.T_out = t_out;
+        a.Nq = (t_out - 1 + p) / s + 1; a.T_out = t_out; a.rg = rg(rate);
         a.y16 = wsp<void>(W.u[i]); a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;   // raw, operand type
-        conv(st.up, a);
+        conv(st.up, a, dtype_dec());
       }
+      rate *= s;                                     // ... and at its output, where the ResBlocks work
       // The ResBlocks of a stage are independent until their mean.  Pair q of all three chains goes out as ONE
       // launch (workgroups of chains with different kernel sizes interleave on the CUs, see rbpair_kernel); a stage
       // whose pairs cannot run fused falls back to one launch per conv, optionally on parallel branches (streams).
@@ -280,7 +289,7 @@ struct Path {
         for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
           // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
           // consumer (next up-sampler / conv_post) while it stages its input, so nothing is accumulated here
-          PairArgs3 a3; a3.n = per_launch;
+          PairArgs3 a3; a3.n = per_launch; a3.rg = rg(rate);
           ConvDesc d1s[3], d2s[3];
           // the chain with the largest kernel first: its workgroups are the longest, so they should start earliest
           int order[3] = {j0, j0 + 1, j0 + 2};
@@ -292,7 +301,7 @@ struct Path {
             d1s[s_] = st.c1[(size_t)j * 3 + q]; d2s[s_] = st.c2[(size_t)j * 3 + q];
             src[(size_t)j] = dst;
           }
-          if (status == QVC_OK) status = be.pair3(d1s, d2s, a3, B, dtype());
+          if (status == QVC_OK) status = be.pair3(d1s, d2s, a3, B, dtype_dec());
         }
       } else {
       be.fork(NB);                                   // branches wait for everything enqueued so far
@@ -304,24 +313,25 @@ struct Path {
           void* dst = q == 1 ? wsp<void>(W.rb[i][(size_t)j]) : wsp<void>(W.ra[i][(size_t)j]);
           const bool last = q == 2;
           if (pair_supported(d1, d2) && d1.lp && d2.lp) {
-            const PairArgs pa = pair_args(j, q, dst);
-            if (status == QVC_OK) status = be.pair(d1, d2, pa, B, dtype());
+            PairArgs3 a1; a1.n = 1; a1.rg = rg(rate);
+            a1.p[0] = pair_args(j, q, dst);
+            if (status == QVC_OK) status = be.pair3(&d1, &d2, a1, B, dtype_dec());
           } else {
             void* xt = wsp<char>(W.xt[i]) + (size_t)j * (size_t)B * (size_t)bs * 2;
             {   // lrelu -> dilated conv -> lrelu (stored already activated)
               ConvArgs a = args(d1);
               a.x = src[(size_t)j]; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out; a.slope_in = 0.1f;
-              a.Nq = t_out; a.T_out = t_out;
+              a.Nq = t_out; a.T_out = t_out; a.rg = rg(rate);
               a.y16 = xt; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 0.1f;
-              conv(d1, a);
+              conv(d1, a, dtype_dec());
             }
             {   // conv -> + x
               ConvArgs a = args(d2);
               a.x = xt; a.x_kind = XK_OP_FM; a.x_bs = bs; a.x_ts = ch; a.T_in = t_out;
-              a.Nq = t_out; a.T_out = t_out;
+              a.Nq = t_out; a.T_out = t_out; a.rg = rg(rate);
               a.res16 = src[(size_t)j]; a.res_bs = bs; a.res_ts = ch;
               a.y16 = dst; a.y16_bs = bs; a.y16_ts = ch; a.slope_out = 1.f;
-              conv(d2, a);
+              conv(d2, a, dtype_dec());
             }
           }
           if (last) be.branch_done(j);
@@ -336,15 +346,16 @@ struct Path {
       mean_input(a, P.stages.size() - 1);
       a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in;
       a.T_in = t_in; a.slope_in = 0.01f; a.reflect = 1;
-      a.Nq = t_in + 1; a.T_out = t_in + 1;
+      a.Nq = t_in + 1; a.T_out = t_in + 1; a.rg = rg(rate);
       a.y32 = post_out; a.y32_bs = (int64_t)(t_in + 1) * P.post_channels; a.y32_ts = P.post_channels;
-      conv(P.conv_post, a);
+      conv(P.conv_post, a, dtype_dec());
     }
   }
 
   void tail(const float* post, float* out, float* y_mb, int F) {
     if (status != QVC_OK) return;
     TailArgs ta{post, reinterpret_cast<const float*>(blob + P.fir_off), out, y_mb, B, F};
+    ta.rg = rg(P.total_up, 1);
     status = be.tail(ta);
   }
 };

@@ -17,6 +17,10 @@ constexpr int kWaves = 4;          // waves per workgroup in the conv kernel (M 
 constexpr int kKStep = 32;         // MFMA 16x16x32: K elements per step
 constexpr int kFragElems = 512;    // one A fragment = 64 lanes x 8 elements
 
+// operand type of the two halves of the path (QVC_BF16X: bf16 WaveNets, f16 generator; they meet at fp32 tensors)
+inline int wn_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_BF16 : c.operand_dtype; }
+inline int dec_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_F16 : c.operand_dtype; }
+
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -230,7 +234,7 @@ inline int validate(const qvc_config& c) {
   if (bad(c.n_fft != 16 || c.hop != 4)) return QVC_ERR_BAD_CONFIG;           // the tail kernel is built for 16/4
   if (bad(c.decoder != QVC_DEC_MULTISTREAM && c.decoder != QVC_DEC_MULTIBAND)) return QVC_ERR_BAD_CONFIG;
   if (bad(c.subbands != 4 || c.fir_taps != 63)) return QVC_ERR_BAD_CONFIG;
-  if (bad(c.operand_dtype != QVC_BF16 && c.operand_dtype != QVC_F16)) return QVC_ERR_BAD_CONFIG;
+  if (bad(c.operand_dtype != QVC_BF16 && c.operand_dtype != QVC_F16 && c.operand_dtype != QVC_BF16X)) return QVC_ERR_BAD_CONFIG;
   return QVC_OK;
 }
 
@@ -473,7 +477,7 @@ inline SpkPlan build_spk_plan(const qvc_config& c) {
   S.n_mel = c.n_mel_channels > 0 ? c.n_mel_channels : 80;
   S.H = c.gin_channels;
   if (S.H <= 0 || S.H % 8 || S.H > 256 || S.n_mel > 1024 ||
-      (c.operand_dtype != QVC_BF16 && c.operand_dtype != QVC_F16)) { S.status = QVC_ERR_BAD_CONFIG; return S; }
+      (c.operand_dtype != QVC_BF16 && c.operand_dtype != QVC_F16 && c.operand_dtype != QVC_BF16X)) { S.status = QVC_ERR_BAD_CONFIG; return S; }
   S.HP = (int)align_up(S.H, 32); S.NW = S.HP / 32; S.KS = S.HP / kKStep;
   int64_t off = 0;
   for (int l = 0; l < kSpkLayers; ++l) {

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   const int o0 = blockIdx.x * kOT;
   const int a0 = o0 >> 2;                   // first band sample owned by this block
   const int f_lo = (o0 >> 4) - 3;           // first frame staged
-  const int L = 4 * (a.F - 1);              // band signal length
+  const int Lpad = 4 * (a.F - 1);           // band signal length of the (padded) buffers
+  const int Fb = ragged_len(a.rg, b, a.F);  // this utterance's frame count (ragged batches): its iSTFT envelope ends there
+  const int L = Fb > 0 ? 4 * (Fb - 1) : 0;  // band signal length of this utterance; samples past it are zeros
   const float* pb = a.post + (size_t)b * a.F * kPostC;
 
   // ---- stage frames [f_lo, f_lo+kNFR) x 72 channels (contiguous in memory), float4 coalesced
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
       const int fr = i / (kPostC / 4), c4 = i - fr * (kPostC / 4);
       const int t = f_lo + fr;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < kChunks && t >= 0 && t < a.F) v[u] = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
+      if (i < kChunks && t >= 0 && t < Fb) v[u] = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
     }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int t = t_hi - d, m = n + 8 - 4 * t;
-        if (t >= 0 && t < a.F && m < 16) {
+        if (t >= 0 && t < Fb && m < 16) {
           const float w = 0.5f - 0.5f * C16b[m];
           num += s_xw[k][t - f_lo][m];
           env += w * w;
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
       y = num / env;
     }
     s_y[k][i] = y;
-    if (a.y_mb && i >= 7 && i < 7 + kOT / 4 && n < L)
-      a.y_mb[((size_t)b * kBands + k) * L + n] = y;
+    if (a.y_mb && i >= 7 && i < 7 + kOT / 4 && n < Lpad)
+      a.y_mb[((size_t)b * kBands + k) * Lpad + n] = y;
   }
   __syncthreads();
 
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
       }
     }
     const int o = o0 + 4 * tid;
-    const int n_out = 4 * L;
+    const int n_out = 4 * Lpad;
+    if (o >= 4 * L) out[0] = out[1] = out[2] = out[3] = 0.f;     // past this utterance's end (4*L is a multiple of 4)
     if (o + 3 < n_out) {
       *reinterpret_cast<float4*>(a.out + (size_t)b * n_out + o) = make_float4(out[0], out[1], out[2], out[3]);
     } else {

@@ -297,6 +297,6 @@ extern "C" int qvc_speaker_embed(const qvc_config* cfg, const void* spk_blob_dev
   if (workspace_bytes < W.bytes) return QVC_ERR_SMALL_BUFFER;
   if ((int64_t)U * spk_partials(F) > (1 << 20)) return QVC_ERR_BAD_ARG;
   SpkHipBackend be{static_cast<hipStream_t>(stream)};
-  return spk_path(S, cfg->operand_dtype, static_cast<const char*>(spk_blob_dev), static_cast<char*>(workspace), W, mel, g,
+  return spk_path(S, dec_dtype(*cfg), static_cast<const char*>(spk_blob_dev), static_cast<char*>(workspace), W, mel, g,
                   U, F, be);
 }

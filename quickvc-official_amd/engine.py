@@ -124,6 +124,32 @@ class QvcEngine:
         return out
 
     @_on_device
+    def infer_batch_ragged(self, unit: torch.Tensor, g: torch.Tensor, noise: torch.Tensor, frames: torch.Tensor,
+                           out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A batch of utterances of DIFFERENT lengths: unit (B,256,Tmax) / noise (B,inter,Tmax) padded (the padding's
+        content is ignored), frames (B,) int32 lengths -> (B,1,Tmax*samples_per_frame); row b holds utterance b's
+        waveform in its first frames[b]*samples_per_frame samples and zeros after."""
+        B, cu, T = unit.shape
+        mc = self.model_config
+        if cu != mc.get("unit_channels", 256) or g.shape != (B, mc["gin_channels"]) or \
+                tuple(noise.shape) != (B, mc["inter_channels"], T) or tuple(frames.shape) != (B,):
+            raise ValueError(f"bad input shapes: unit {tuple(unit.shape)}, g {tuple(g.shape)}, noise {tuple(noise.shape)}, frames {tuple(frames.shape)}")
+        if frames.device.type != "cuda":                       # host-side lengths can be validated for free
+            if int(frames.min()) < 2 or int(frames.max()) > T:
+                raise ValueError(f"frames must lie in [2, {T}], got [{int(frames.min())}, {int(frames.max())}]")
+        unit, g, noise = (self._f32(t, self.device) for t in (unit, g, noise))
+        lens = frames.to(device=self.device, dtype=torch.int32).contiguous()
+        if out is None:
+            out = torch.empty(B, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
+        if ws is None:
+            ws = self.workspace(B, T)
+        st = self.lib.qvc_infer_batch_ragged(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
+                                             noise.data_ptr(), out.data_ptr(), B, T, lens.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_infer_batch_ragged")
+        return out
+
+    @_on_device
     def speaker_embed(self, mel: torch.Tensor) -> torch.Tensor:
         """SpeakerEncoder.embed_utterance for a batch (models.py:528-546): mel (U, n_mel, F) -> g (U, gin)."""
         if mel.dim() != 3 or mel.shape[1] != int(self.cfg.n_mel_channels) or mel.shape[2] < 1:

@@ -16,7 +16,8 @@ QVC_OK = 0
 QVC_BF16, QVC_F16 = 0, 1
 QVC_DEC_ISTFT, QVC_DEC_MULTIBAND, QVC_DEC_MULTISTREAM = 0, 1, 2
 QVC_MAX_UPS = QVC_MAX_RESBLOCKS = 4
-DTYPES = {"bf16": QVC_BF16, "f16": QVC_F16, "fp16": QVC_F16}
+QVC_BF16X = 2     # bf16 WaveNet half + f16 generator (include/qvc.h)
+DTYPES = {"bf16": QVC_BF16, "f16": QVC_F16, "fp16": QVC_F16, "bf16x": QVC_BF16X}
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libqvc_hip.so")
 
@@ -66,6 +67,8 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_workspace_bytes.argtypes = [cfgp, I, I]
         lib.qvc_infer_batch.restype = ctypes.c_int
         lib.qvc_infer_batch.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
+        lib.qvc_infer_batch_ragged.restype = ctypes.c_int
+        lib.qvc_infer_batch_ragged.argtypes = [cfgp, V, V, V, V, V, I, I, V, V, L, V]
         lib.qvc_aux_create.restype = ctypes.c_int
         lib.qvc_aux_create.argtypes = [P(V)]
         lib.qvc_aux_destroy.restype = ctypes.c_int
@@ -128,7 +131,7 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 5:
+        if lib.qvc_abi_version() != 6:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -333,3 +333,25 @@ class SynthesizerTrn(nn.Module):
             noise = torch.randn(unit.shape[0], self.model_config["inter_channels"], unit.shape[2],
                                 device=unit.device, dtype=torch.float32)
         return eng.infer_batch(unit, g.reshape(g.shape[0], -1), noise)
+
+    @torch.no_grad()
+    def infer_ragged(self, units, g: Tensor, noises=None):
+        """Utterances of DIFFERENT lengths in one launch sequence (the reference converts any length per call,
+        convert.py:58-86): ``units`` is a list of (256, F_b) / (1, 256, F_b) tensors, g (B, gin) or (B, gin, 1),
+        ``noises`` an optional list of (inter, F_b) draws.  Returns a list of (1, 320*F_b) fp32 waveforms -- each
+        equal to the utterance converted alone (every conv sees ITS sequence end, not the padded batch's)."""
+        eng = self.engine()
+        dev = eng.device
+        us = [u.reshape(-1, u.shape[-1]) for u in units]
+        lens = [int(u.shape[-1]) for u in us]
+        B, tmax, inter = len(us), max(lens), self.model_config["inter_channels"]
+        unit = torch.zeros(B, us[0].shape[0], tmax, device=dev, dtype=torch.float32)
+        noise = torch.zeros(B, inter, tmax, device=dev, dtype=torch.float32)
+        for b, u in enumerate(us):
+            unit[b, :, :lens[b]] = u.to(dev, torch.float32)
+            n = noises[b].reshape(inter, -1).to(dev, torch.float32) if noises is not None else \
+                torch.randn(inter, lens[b], device=dev, dtype=torch.float32)
+            noise[b, :, :lens[b]] = n
+        out = eng.infer_batch_ragged(unit, g.reshape(B, -1), noise, torch.tensor(lens, dtype=torch.int32))
+        spf = self.samples_per_frame
+        return [out[b, :, :lens[b] * spf] for b in range(B)]

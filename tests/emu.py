@@ -18,6 +18,8 @@ def load_emu():
     P, I, Lg, V = ctypes.POINTER, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
     lib.qvc_emu_infer_batch.restype = ctypes.c_int
     lib.qvc_emu_infer_batch.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, Lg]
+    lib.qvc_emu_infer_batch_ragged.restype = ctypes.c_int
+    lib.qvc_emu_infer_batch_ragged.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, V, Lg]
     lib.qvc_emu_speaker_embed.restype = ctypes.c_int
     lib.qvc_emu_speaker_embed.argtypes = [P(L.QvcConfig), V, V, V, I, I, V, Lg]
     lib.qvc_emu_enc_q.restype = ctypes.c_int
@@ -69,6 +71,31 @@ def emu_infer(model_config, sd, unit, g, noise, dtype="f16", taps=None):
         taps["ups0"] = ws[off:off + B * t1 * ch0 * 2].view(td).reshape(B, t1, ch0).float()
         off = emu.qvc_emu_tap_offset(ctypes.byref(cfg), B, T, 2)
         taps["rb0"] = ws[off:off + B * t1 * ch0 * 2].view(td).reshape(B, t1, ch0).float()
+    return out
+
+
+def emu_infer_ragged(model_config, sd, unit, g, noise, frames, dtype="f16"):
+    """Host replay of qvc_infer_batch_ragged: padded unit / noise (B, C, Tmax), frames = per-utterance lengths."""
+    from quickvc_official_amd import lib as L
+    hip = L.load_library()
+    emu = load_emu()
+    mc = dict(model_config, operand_dtype=dtype)
+    cfg = L.make_config(mc)
+    blob = L.pack_weights(hip, cfg, sd)
+    B, _, T = unit.shape
+    n_ws = int(hip.qvc_workspace_bytes(ctypes.byref(cfg), B, T))
+    raw = torch.zeros(n_ws + 256, dtype=torch.uint8)
+    shift = (-raw.data_ptr()) % 256
+    ws = raw[shift:shift + n_ws]
+    spf = mc["gen_istft_hop_size"] * mc["subbands"]
+    for u in mc["upsample_rates"]:
+        spf *= u
+    out = torch.full((B, 1, T * spf), float("nan"))
+    unit, g, noise = unit.float().contiguous(), g.float().contiguous(), noise.float().contiguous()
+    lens = torch.as_tensor(frames, dtype=torch.int32).contiguous()
+    st = emu.qvc_emu_infer_batch_ragged(ctypes.byref(cfg), blob.data_ptr(), unit.data_ptr(), g.data_ptr(), noise.data_ptr(),
+                                        out.data_ptr(), B, T, lens.data_ptr(), ws.data_ptr(), n_ws)
+    assert st == 0, hip.qvc_status_string(st)
     return out
 
 

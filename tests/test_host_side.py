@@ -29,11 +29,39 @@ def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "qvc.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
-    assert len(names) >= 27
+    assert len(names) >= 28
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 5
+    assert built.qvc_abi_version() == 6
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
+
+
+def test_no_hot_kernel_spills_to_scratch(built):
+    """hipcc's per-kernel resource remarks (kept by build.py next to the objects): the MFMA kernels must not use
+    scratch memory and must keep the occupancy their launch geometry assumes (two 4-wave workgroups or one 8-wave
+    workgroup per CU = 2 waves per SIMD).  A by-reference use of a by-value kernel argument once sent the whole
+    argument struct to scratch and halved the occupancy of the pair kernel -- silently, at +60 % run time."""
+    import glob
+    # the instantiations the shipped config launches (other widths have variants that do spill; they are correct, just slower)
+    hot = ("rbpair_kernelIDF16_Li2ELi10ELi4ELi4E", "rbpair_kernelIDF16_Li2ELi10ELi8ELi8E", "conv_mfma_kernelIDF16_",
+           "wn_stack_kernelIDF16_Li3ELi0ELi12E", "wn_stack_kernelIDF16_Li3ELi1ELi12E", "wn_layer_kernelIDF16_Li2ELb0ELi12E",
+           "wn_layer_kernelIDF16_Li2ELb1ELi12E", "rbpair_persist_kernelIDF16_Li2ELi10ELi16ELi256E")
+    seen = set()
+    for path in glob.glob(os.path.join(ROOT, "quickvc-official_amd", "csrc", "_obj", "qvc_conv_f16.remarks.txt")):
+        name = None
+        for line in open(path):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            tag = next((h for h in hot if name and h in name), None)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and tag:
+                assert int(m.group(1)) == 0, (name, line)
+                seen.add(tag)
+            m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
+            if m and tag and "rbpair_kernel" in tag:
+                assert int(m.group(1)) >= 2, (name, line)
+    assert seen == set(hot), set(hot) - seen
 
 
 def test_package_fails_loudly_without_gpu_or_library(built, monkeypatch):
@@ -232,6 +260,28 @@ def test_host_emulation_of_launch_sequence_matches_oracle(built, name, dtype, mi
     assert snr_db(gold["o"], out.reshape(-1).numpy()) >= min_db
 
 
+def test_ragged_batch_host_emulation_matches_per_utterance_oracle(built):
+    """qvc_infer_batch_ragged's launch sequence replayed on the CPU: utterances of lengths 21 / 13 / 5 padded to 21
+    in ONE batch (padding filled with junk) against the oracle run on each utterance alone -- every conv, WaveNet
+    layer and the iSTFT envelope must see its own sequence end (convert.py:58-86 converts any length per line)."""
+    from emu import emu_infer_ragged
+    entry, _ = load_case("odd")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    cfg = entry["config"]
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    lens = [21, 13, 5]
+    unit, g, noise = make_synthetic_inputs(3, 21, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=70)
+    pad_u, pad_n = unit.clone(), noise.clone()
+    for b, n in enumerate(lens):
+        pad_u[b, :, n:] = 1e3 * (b + 1)                           # junk that must never reach a result
+        pad_n[b, :, n:] = -7.0
+    out = emu_infer_ragged(cfg, sd, pad_u, g, pad_n, lens, "f16")
+    for b, n in enumerate(lens):
+        ref = oracle.infer_from_g(sd, cfg, unit[b:b + 1, :, :n], g[b:b + 1].unsqueeze(-1), noise[b:b + 1, :, :n])
+        assert snr_db(ref[0], out[b, :, :320 * n]) >= 45.0, (b, n)
+        assert float(out[b, :, 320 * n:].abs().max()) == 0.0 if n < 21 else True      # zeros after the utterance's end
+
+
 def test_config_and_checkpoint_drop_in(tmp_path, built):
     import quickvc_official_amd as q
     from quickvc_official_amd.synth import make_synthetic_state_dict
@@ -284,14 +334,28 @@ ok = bool((blob == torch.arange(1000, dtype=torch.int64).to(torch.uint8)).all())
 mine = qd.shard_indices(10, rank, world)
 wall = qd.max_over_ranks(1.0 + rank, torch.device("cpu"))
 total = qd.sum_over_ranks(float(len(mine)), torch.device("cpu"))
-print(json.dumps({{"rank": rank, "ok": ok, "mine": mine, "wall": wall, "total": total}}))
+# the CLI's shard -> batches plan for this rank, from the .npy headers alone (convert.rank_plan)
+from quickvc_official_amd.convert import rank_plan
+items = [ln.strip().split("|") for ln in open({listfile!r}) if ln.strip()]
+lengths, cli_mine, batches = rank_plan(items, rank, world, 4)
+print(json.dumps({{"rank": rank, "ok": ok, "mine": mine, "wall": wall, "total": total, "cli_mine": cli_mine,
+                  "batches": batches, "lengths": lengths}}))
 dist.destroy_process_group()
 """
 
 
 def test_world_size_2_broadcast_and_sharding_gloo(tmp_path):
+    # a 13-line list whose sources are .npy unit files of different lengths (only their headers are read by the plan)
+    rs = np.random.RandomState(3)
+    lens = [int(x) for x in rs.randint(30, 300, size=13)]
+    lines = []
+    for i, n in enumerate(lens):
+        np.save(str(tmp_path / f"u{i}.npy"), np.zeros((n, 256), dtype=np.float32))
+        lines.append(f"title{i}|{tmp_path}/u{i}.npy|{tmp_path}/spk{i % 3}.wav")
+    listfile = tmp_path / "convert.txt"
+    listfile.write_text("\n".join(lines) + "\n")
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
+    script.write_text(_WORKER.format(root=ROOT, listfile=str(listfile)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
@@ -304,6 +368,14 @@ def test_world_size_2_broadcast_and_sharding_gloo(tmp_path):
     assert all(d["ok"] for d in outs)
     assert outs[0]["mine"] == [0, 2, 4, 6, 8] and outs[1]["mine"] == [1, 3, 5, 7, 9]
     assert all(d["wall"] == 2.0 and d["total"] == 10.0 for d in outs)
+    # the two ranks' CLI plans partition the list, balance the frames, and batch similar lengths together
+    assert outs[0]["lengths"] == outs[1]["lengths"] == lens
+    assert sorted(outs[0]["cli_mine"] + outs[1]["cli_mine"]) == list(range(13))
+    loads = [sum(lens[i] for i in d["cli_mine"]) for d in outs]
+    assert abs(loads[0] - loads[1]) <= max(lens)
+    for d in outs:
+        assert sorted(i for b in d["batches"] for i in b) == sorted(d["cli_mine"])
+        assert all(len(b) <= 4 and min(lens[i] for i in b) >= 0.75 * max(lens[i] for i in b) for b in d["batches"])
 
 
 def test_frontend_and_cli_planning():
@@ -322,11 +394,19 @@ def test_frontend_and_cli_planning():
     wav[4000:12000] = 0.5 * np.sin(2 * np.pi * 220 * np.arange(8000) / 16000)
     t = F.trim(wav, top_db=20)
     assert 7000 <= len(t) <= 10500 and len(t) < len(wav)            # silence dropped, tone kept (512-sample hops)
-    mel = F.wave_to_mel(torch.from_numpy(wav).unsqueeze(0), 1280, 80, 16000, 320, 1280, 0.0, None)
+    mel = oracle.wave_to_mel(torch.from_numpy(wav).unsqueeze(0), torch.from_numpy(basis), 1280, 320, 1280)
     assert mel.shape == (1, 80, 50) and torch.isfinite(mel).all()  # 16000 samples / hop 320 (mel_processing.py:79-98)
     assert float(mel[:, :, 20:30].max()) > float(mel[:, :, :5].max()) + 3.0
+    # ragged batches: length-sorted runs of at most `batch`, cut where the padding would exceed 25 %
     plan = plan_batches([81, 250, 81, 250, 250, 120], batch=2)
     assert plan == [[1, 3], [4], [5], [0, 2]]
+    plan = plan_batches([250, 240, 181, 81, 40, 239, 200], batch=4)
+    assert plan == [[0, 1, 5, 6], [2], [3], [4]]
+    lens = list(np.random.RandomState(0).randint(40, 400, size=1000))
+    plan = plan_batches(lens, batch=32)
+    assert sorted(i for b in plan for i in b) == list(range(1000)) and max(len(b) for b in plan) <= 32
+    assert all(min(lens[i] for i in b) >= 0.75 * max(lens[i] for i in b) for b in plan)
+    assert len(plan) <= 60                                          # a corpus does not degenerate to batch-1 launches
     ref = os.path.join(ROOT, "..", "reference", "test_data", "p225_001.wav")
     if os.path.exists(ref):                                         # container only: the reference's own demo input
         w = F.load_wav(ref, 16000)

@@ -76,3 +76,27 @@ def test_weight_norm_fold_matches_torch():
         w = oracle.fold_weight_norm(conv.weight_v.data, conv.weight_g.data)
         x = torch.randn(1, shape[1], 40)
         assert torch.allclose(torch.nn.functional.conv1d(x, w, conv.bias), conv(x), atol=1e-6)
+
+
+def test_oracle_mel_frontend_reproduces_reference_fixtures():
+    """oracle.wave_to_spec / wave_to_mel (mel_processing.py:15-98 restated) against tests/golden/mel.npz, which the
+    reference's own module produced (make_golden_mel.py: stub librosa returning this repo's filter bank).  The
+    linear spectrogram is stored as a strided subsample plus its sum of squares."""
+    import os
+    import sys
+    import helpers
+    sys.path.insert(0, helpers.GOLDEN)
+    from make_golden_mel import synth_wave
+    from quickvc_official_amd.frontend import mel_basis
+    gold = dict(np.load(os.path.join(helpers.GOLDEN, "mel.npz")))
+    basis = torch.from_numpy(mel_basis(16000, 1280, 80, 0.0, None))
+    for n, seed in zip(gold["lengths"], gold["seeds"]):
+        wave = synth_wave(int(n), int(seed))
+        spec = oracle.wave_to_spec(wave, 1280, 320, 1280)
+        assert tuple(spec.shape) == tuple(gold[f"spec{int(n)}::shape"])
+        flat = spec.reshape(-1)
+        stride = max(1, -(-flat.numel() // 8192))
+        assert np.abs(flat[::stride].numpy() - gold[f"spec{int(n)}"]).max() <= 1e-5 * float(spec.abs().max())
+        assert abs(float(spec.double().pow(2).sum()) / float(gold[f"spec{int(n)}::sumsq"][0]) - 1.0) <= 1e-6
+        mel = oracle.wave_to_mel(wave, basis, 1280, 320, 1280)
+        assert np.abs(mel.numpy() - gold[f"mel{int(n)}"]).max() <= 1e-5

@@ -7,7 +7,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import quickvc_official_amd  # noqa: E402,F401
-from quickvc_official_amd.frontend import MelFrontend, wave_to_mel  # noqa: E402
+from quickvc_official_amd.frontend import MelFrontend, mel_basis  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import qvc_oracle as oracle  # noqa: E402  (developer tool: the comparator lives with the oracle)
+
+BASIS = torch.from_numpy(mel_basis(16000, 1280, 80, 0.0, None))
+
+
+def wave_to_mel(wave, *_):
+    return oracle.wave_to_mel(wave.cpu(), BASIS, 1280, 320, 1280).to(wave.device)
 
 
 def timed(fn, n=50):

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r01_traffic.json.
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r02_traffic.json.
 
 HBM bytes per launch, per kernel, as MI355X_MICROARCH.md (HBM section) prescribes: separate passes for
 FETCH_SIZE and WRITE_SIZE, both in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
 reads, so it is doubled; WRITE_SIZE is taken as is.  (Narrower access widths are uncalibrated.)
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_traffic.json
 """
 import collections
 import csv
@@ -26,6 +26,9 @@ def load(d, counter):
 
 
 def pretty(name):
+    m = re.search(r"rbpair_persist_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)E", name)
+    if m:
+        return f"rbpair_persist<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)}>"
     m = re.search(r"rbpair_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi\d+E", name)
     if m:
         return f"rbpair<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)}>"
@@ -55,7 +58,10 @@ def main():
         res[pretty(k)] = {"launches_profiled": launches, "fetch_bytes_raw_per_launch": fetch,
                           "write_bytes_per_launch": write, "hbm_bytes_per_launch": 2.0 * fetch + write,
                           "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported"}
-    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernel_source_sha1
+    json.dump({"kernel_source_sha1": kernel_source_sha1(), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     for k, v in res.items():
         print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")
 
