@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 6
+#define QVC_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -59,9 +59,9 @@ enum {
 enum {
   QVC_BF16 = 0,  /* bf16 operands, fp32 accumulate (BASELINE.json configs 2-5) */
   QVC_F16 = 1,   /* fp16 operands, fp32 accumulate (same MFMA rate, 3 more mantissa bits) */
-  QVC_BF16X = 2  /* mixed: bf16 operands in the WaveNet half (enc_p / enc_q / flow), fp16 in the generator, whose
-                    ~75 chained convs + exp() are where bf16's 8-bit mantissa costs the waveform SNR;
-                    the two halves meet at fp32 tensors (z), so no kernel mixes operand types */
+  QVC_BF16X = 2  /* mixed: bf16 MFMA operands in the fused ResBlock pairs (80 % of the path's FLOPs) with their residual
+                    stream kept in fp16 (same bytes; the identity path of 18 chained pairs keeps 11 mantissa bits), fp16
+                    everywhere else.  All-bf16 misses the 40 dB waveform bar (34 dB measured); this mode meets it */
 };
 
 #define QVC_MAX_UPS 4
@@ -151,6 +151,31 @@ int qvc_infer_batch_ragged(const qvc_config* cfg, const void* blob_dev,
                            const float* unit, const float* g, const float* noise, float* out,
                            int32_t batch, int32_t max_frames, const int32_t* frames_dev,
                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- streaming: one hop of new unit frames per call, state in a caller-owned buffer (BASELINE configs[4]) -----
+ * The reference converts whole utterances; every op of the path is a bounded, symmetric
+ * convolution, so the path also runs as a pipeline of segments (enc_p | each coupling layer | conv_pre+stage 0 |
+ * stage 1+conv_post+iSTFT), each fed from a ring that keeps the last 2*H frames of its input: a frame costs
+ * (2*H + hop)/hop of its offline cost per segment (1.08x at hop 320) and the output lags the input by
+ * qvc_stream_lag_frames() frames -- the look-ahead a non-causal network needs.  Sequence starts and ends are
+ * exact: every kernel masks rows by the window's absolute position.  csrc/qvc_stream.h has the details.
+ *   state      caller-owned device buffer of qvc_stream_state_bytes(), ZEROED before a stream's first step
+ *   unit_new   (B, unit_channels, hop) fp32: unit frames [pos[b], pos[b] + hop) (anything past the sequence end)
+ *   noise_new  (B, inter_channels, hop) fp32: the N(0,1) draw of models.py:94 for frames
+ *              [pos[b] - qvc_stream_noise_lag_frames(), ... + hop)  (the frames enc_p completes in this step)
+ *   out        (B, hop * samples_per_frame) fp32: frames [pos[b] - lag, pos[b] - lag + hop); zeros outside [0, len[b])
+ *   pos_dev, len_dev  device int32 [B]: first new frame of this step / sequence length (a large number while unknown).
+ *              The caller advances pos by hop between steps (device arrays: a captured graph replays unchanged).
+ * To flush a stream of length L keep stepping (inputs ignored) until pos - lag >= L.
+ */
+int64_t qvc_stream_state_bytes(const qvc_config* cfg, int32_t batch, int32_t hop);
+int64_t qvc_stream_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t hop);
+int32_t qvc_stream_lag_frames(const qvc_config* cfg);
+int32_t qvc_stream_noise_lag_frames(const qvc_config* cfg);
+int qvc_stream_step(const qvc_config* cfg, const void* blob_dev, void* state, int64_t state_bytes,
+                    const float* unit_new, const float* g, const float* noise_new, float* out,
+                    int32_t batch, int32_t hop, const int32_t* pos_dev, const int32_t* len_dev,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- optional fork/join resources: lets the three independent ResBlocks of an MRF stage
  * (models.py:378-384) run as parallel branches (two auxiliary non-blocking streams + events), so a

@@ -10,6 +10,7 @@
 #include <new>
 #include <vector>
 #include "qvc_path.h"
+#include "qvc_stream.h"
 #include "qvc_pack_util.h"
 
 namespace qvc {
@@ -81,6 +82,9 @@ struct HipBackend {
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
   int zero(void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; }
+  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+  }
 };
 using Ctx = Path<HipBackend>;
 
@@ -131,8 +135,9 @@ struct TimedBackend {
     mark();
     char name[48];
     // one kernel symbol serves 1..3 chains per launch; the record's flops / bytes are those of the whole launch
-    if (nf >= 100) std::snprintf(name, sizeof(name), "rbpair_persist<%s,MF%d,NF%d>", dtype == QVC_F16 ? "f16" : "bf16", d1[0].MF, nf - 100);
-    else std::snprintf(name, sizeof(name), "rbpair<%s,MF%d,NF%d,WM%d>", dtype == QVC_F16 ? "f16" : "bf16", d1[0].MF, nf, d1[0].WM);
+    const char* tn = dtype == QVC_F16 ? "f16" : (dtype == QVC_BF16X ? "bf16x" : "bf16");
+    if (nf >= 100) std::snprintf(name, sizeof(name), "rbpair_persist<%s,MF%d,NF%d>", tn, d1[0].MF, nf - 100);
+    else std::snprintf(name, sizeof(name), "rbpair<%s,MF%d,NF%d,WM%d>", tn, d1[0].MF, nf, d1[0].WM);
     double fl = 0, by = 0;
     for (int i = 0; i < a.n; ++i) {
       const double outs = (double)batch * a.p[i].T * a.p[i].C;
@@ -298,6 +303,53 @@ int qvc_infer_batch_ragged(const qvc_config* cfg, const void* blob_dev, const fl
   c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
   c.tail(c.wsp<float>(W.post), out, nullptr, max_frames * P.total_up + 1);
   return c.status != QVC_OK ? c.status : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
+}
+
+int64_t qvc_stream_state_bytes(const qvc_config* cfg, int32_t batch, int32_t hop) {
+  if (!cfg || batch <= 0 || hop <= 0) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  const StreamGeom G = stream_geom(P, hop);
+  if (G.status != QVC_OK) return G.status;
+  return carve_stream_state(P, G, batch).bytes;
+}
+
+int64_t qvc_stream_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t hop) {
+  if (!cfg || batch <= 0 || hop <= 0) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  const StreamGeom G = stream_geom(P, hop);
+  if (G.status != QVC_OK) return G.status;
+  return carve_stream_scratch(P, G, batch).bytes;
+}
+
+int32_t qvc_stream_lag_frames(const qvc_config* cfg) {
+  if (!cfg) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  const StreamGeom G = stream_geom(P, 1);
+  return G.status != QVC_OK ? G.status : G.lag();
+}
+
+int32_t qvc_stream_noise_lag_frames(const qvc_config* cfg) {
+  if (!cfg) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  const StreamGeom G = stream_geom(P, 1);
+  return G.status != QVC_OK ? G.status : G.He;
+}
+
+int qvc_stream_step(const qvc_config* cfg, const void* blob_dev, void* state, int64_t state_bytes, const float* unit_new,
+                    const float* g, const float* noise_new, float* out, int32_t batch, int32_t hop, const int32_t* pos_dev,
+                    const int32_t* len_dev, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!cfg || !blob_dev || !state || !unit_new || !g || !noise_new || !out || !pos_dev || !len_dev || !workspace || batch <= 0 || hop <= 0)
+    return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  const StreamGeom G = stream_geom(P, hop);
+  if (G.status != QVC_OK) return G.status;
+  if (state_bytes < carve_stream_state(P, G, batch).bytes || workspace_bytes < carve_stream_scratch(P, G, batch).bytes) return QVC_ERR_SMALL_BUFFER;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(blob_dev) & 255) || (reinterpret_cast<uintptr_t>(state) & 255))
+    return QVC_ERR_BAD_ARG;
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
+  const int st = stream_step(P, static_cast<const char*>(blob_dev), static_cast<char*>(state), static_cast<char*>(workspace), unit_new, g,
+                             noise_new, out, batch, hop, pos_dev, len_dev, be);
+  return st != QVC_OK ? st : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
 }
 
 int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,

@@ -3,4 +3,6 @@
 namespace qvc { template int launch_conv_typed<__bf16>(const ConvDesc&, const ConvArgs&, int, int, void*, int*);
 template int launch_wn_stack_typed<__bf16>(const ConvDesc&, const WnStackArgs&, int, void*);
 template int launch_wn_typed<__bf16>(const ConvDesc&, const WnArgs&, int, void*, int*);
-template int launch_pair_typed<__bf16>(const ConvDesc*, const PairArgs3&, int, void*, int*); }
+template int launch_pair_typed<__bf16, __bf16>(const ConvDesc*, const PairArgs3&, int, void*, int*);
+// QVC_BF16X: bf16 operands, f16 residual stream
+template int launch_pair_typed<__bf16, _Float16>(const ConvDesc*, const PairArgs3&, int, void*, int*); }

@@ -4,4 +4,4 @@
 namespace qvc { template int launch_conv_typed<_Float16>(const ConvDesc&, const ConvArgs&, int, int, void*, int*);
 template int launch_wn_stack_typed<_Float16>(const ConvDesc&, const WnStackArgs&, int, void*);
 template int launch_wn_typed<_Float16>(const ConvDesc&, const WnArgs&, int, void*, int*);
-template int launch_pair_typed<_Float16>(const ConvDesc*, const PairArgs3&, int, void*, int*); }
+template int launch_pair_typed<_Float16, _Float16>(const ConvDesc*, const PairArgs3&, int, void*, int*); }

@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include "qvc_kernels.h"
 #include "qvc_launch_util.h"
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int cpr = a.CinP >> 3;                                  // 16-byte chunks per row
   const Swz sm = swz_mode(cpr);
   const int t_base = q0 - a.left;                               // input frame of tile row 0
-  const int Tin = ragged_len(a.rg, b, a.T_in);                  // this utterance's input length (ragged batches)
+  const int Tin = ragged_len(a.rg, b, a.T_in);                  // this utterance's input rows are [Tlo, Tin) (ragged batches,
+  const int Tlo = ragged_lo(a.rg, b);                           // streaming windows); rows outside read as the conv's zero padding
   if (a.rg.lens && t_base >= Tin + a.reflect) return;           // tile past the end of the utterance: nothing anybody reads
 
   // ------------------------------------------------------------------ stage the activation tile
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
         bool ok; int src;
-        if (a.reflect) { ok = ti >= 0 && ti <= Tin; src = ti == 0 ? 1 : ti - 1; }
-        else { ok = ti >= 0 && ti < Tin; src = ti; }
+        if (a.reflect) { ok = ti >= Tlo && ti <= Tin; src = ti == Tlo ? Tlo + 1 : ti - 1; }
+        else { ok = ti >= Tlo && ti < Tin; src = ti; }
         ok = ok && idx < total && (c8 * 8 < a.Cin);
         v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
         if (ok) {
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
         bool ok; int src;
-        if (a.reflect) { ok = ti >= 0 && ti <= Tin; src = ti == 0 ? 1 : ti - 1; }
-        else { ok = ti >= 0 && ti < Tin; src = ti; }
+        if (a.reflect) { ok = ti >= Tlo && ti <= Tin; src = ti == Tlo ? Tlo + 1 : ti - 1; }
+        else { ok = ti >= Tlo && ti < Tin; src = ti; }
         ok = ok && idx < total && (c8 * 8 < a.Cin);
         v1[u] = make_uint4(0u, 0u, 0u, 0u); v2[u] = v1[u]; v3[u] = v1[u];
         if (ok) {
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int idx = base + u * 256;
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = t_base + r;
-        const bool ok = idx < total && ti >= 0 && ti < Tin && (c8 * 8 < a.Cin);
+        const bool ok = idx < total && ti >= Tlo && ti < Tin && (c8 * 8 < a.Cin);
         v[u] = make_uint4(0u, 0u, 0u, 0u);
         if (ok) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.x_ts + c8 * 8);
         dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int c = idx / R, r = idx - c * R;
         const int ti = t_base + r;
         v[u] = 0.f;
-        if (idx < total && c < a.Cin && ti >= 0 && ti < Tin) v[u] = xb[(size_t)c * a.x_ts + ti];
+        if (idx < total && c < a.Cin && ti >= Tlo && ti < Tin) v[u] = xb[(size_t)c * a.x_ts + ti];
         dst[u] = idx < total ? r * rowbytes + (((c >> 3) ^ swz(r, sm)) << 4) + (c & 7) * 2 : -1;
       }
 #pragma unroll
@@ -515,11 +517,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 //
 // Rows are lane-packed (ConvDesc::lp): a lane's MF accumulator quads are 4*MF consecutive channels, so with an
 // even MF the intermediate goes to LDS and the residual / result move through memory in 16-byte pieces.
-template <typename T, int MF, int NF, int WM, int NWV>
+// TS = type of the residual STREAM in memory (x, y); T = MFMA operand type.  They differ in the mixed mode
+// (QVC_BF16X: bf16 operands, f16 stream): the identity path of 18 chained pairs then carries 11 mantissa bits --
+// rounding it to bf16 at every pair is what costs all-bf16 its waveform SNR (measured) -- at the same bytes.
+template <typename T, int MF, int NF, int WM, int NWV, typename TS = T>
 __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   using O = Op<T>;
   using frag = typename O::frag;
   using quad = typename O::quad;
+  using OS = Op<TS>;
+  using sfrag = typename OS::frag;
+  using squad = typename OS::quad;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = NWV / WM;
   constexpr int NTHR = NWV * 64;
@@ -544,9 +552,10 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   const int rowbytes = a.CP * 2;
   const int cpr = a.CP >> 3;
   const Swz sm = swz_mode(cpr);
-  const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
+  const TS* xb = static_cast<const TS*>(a.x) + (size_t)b * a.bs;
   const int cb = wm * MF * 16 + lq * 4 * MF;   // first of this lane's 4*MF consecutive channels
-  const int Tb = ragged_len(A.rg, b, a.T);     // this utterance's length: both convs zero-pad at ITS end
+  const int Tb = ragged_len(A.rg, b, a.T);     // this utterance occupies rows [Tlo, Tb): both convs zero-pad at ITS ends
+  const int Tlo = ragged_lo(A.rg, b);
   if (q0 >= Tb) return;                        // tile past the end of the utterance (ragged batches)
 
   if (!QVC_ABL(0)) {   // ---- stage lrelu(x): every load of the tile is in flight before the first conversion
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         const int idx = base + u * NTHR;
         const int ti = t_base + r;
         v[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (idx < total && ti >= 0 && ti < Tb && c8 * 8 < a.C) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
+        if (idx < total && ti >= Tlo && ti < Tb && c8 * 8 < a.C) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.C + c8 * 8);
         c8 += cstep; r += rstep;
         if (c8 >= cpr) { c8 -= cpr; ++r; }
       }
@@ -573,8 +582,16 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
       for (int u = 0; u < kU; ++u) {
         const int idx = base + u * NTHR;
         if (idx < total) {
-          frag h; __builtin_memcpy(&h, &v[u], 16);
-          *reinterpret_cast<frag*>(smem + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = lrelu8<T>(h, a.slope);
+          frag o;
+          if constexpr (std::is_same<T, TS>::value) {
+            frag h; __builtin_memcpy(&h, &v[u], 16);
+            o = lrelu8<T>(h, a.slope);
+          } else {                                   // stream type -> fp32 -> activation -> operand type
+            sfrag h; __builtin_memcpy(&h, &v[u], 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = O::cvt(lrelu((float)h[e], a.slope));
+          }
+          *reinterpret_cast<frag*>(smem + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = o;
         }
         c8 += cstep; r += rstep;
         if (c8 >= cpr) { c8 -= cpr; ++r; }
@@ -599,7 +616,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
     for (int n = 0; n < NF1; ++n) {
       const int jr = wn * (NF1 * 16) + n * 16 + lrow;            // intermediate row <-> frame q0 - h2 + jr
       const int f = q0 - h2 + jr;
-      const bool inside = f >= 0 && f < Tb;                      // conv2 zero-pads outside [0, T)
+      const bool inside = f >= Tlo && f < Tb;                      // conv2 zero-pads outside [0, T)
       char* rowp = smem + jr * rowbytes;
       const int sw = swz(jr, sm);
       if constexpr (kWide) {
@@ -649,8 +666,8 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
     float4 bias[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b2 + cb + m * 4);
-    const T* xres = static_cast<const T*>(a.x) + (size_t)b * a.bs;
-    T* yb = static_cast<T*>(a.y) + (size_t)b * a.bs;
+    const TS* xres = static_cast<const TS*>(a.x) + (size_t)b * a.bs;
+    TS* yb = static_cast<TS*>(a.y) + (size_t)b * a.bs;
     const int qw = q0 + wn * (NF * 16) + lrow;
     // All residual loads go out before the first store: x and y may alias as far as the compiler knows, so a
     // load-add-store per fragment compiles to load, s_waitcnt vmcnt(0), store -- MF*NF serialised memory round
@@ -675,17 +692,17 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
           if (q >= Tb) continue;
-          frag r8; __builtin_memcpy(&r8, &rr[m / 2][n], 16);
-          frag h;
-          h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
-          h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r8[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r8[3]);
-          h[4] = O::cvt(acc[m + 1][n][0] + bias[m + 1].x + (float)r8[4]); h[5] = O::cvt(acc[m + 1][n][1] + bias[m + 1].y + (float)r8[5]);
-          h[6] = O::cvt(acc[m + 1][n][2] + bias[m + 1].z + (float)r8[6]); h[7] = O::cvt(acc[m + 1][n][3] + bias[m + 1].w + (float)r8[7]);
-          *reinterpret_cast<frag*>(yb + (size_t)q * a.C + v) = h;
+          sfrag r8; __builtin_memcpy(&r8, &rr[m / 2][n], 16);
+          sfrag h;
+          h[0] = OS::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = OS::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
+          h[2] = OS::cvt(acc[m][n][2] + bias[m].z + (float)r8[2]); h[3] = OS::cvt(acc[m][n][3] + bias[m].w + (float)r8[3]);
+          h[4] = OS::cvt(acc[m + 1][n][0] + bias[m + 1].x + (float)r8[4]); h[5] = OS::cvt(acc[m + 1][n][1] + bias[m + 1].y + (float)r8[5]);
+          h[6] = OS::cvt(acc[m + 1][n][2] + bias[m + 1].z + (float)r8[6]); h[7] = OS::cvt(acc[m + 1][n][3] + bias[m + 1].w + (float)r8[7]);
+          *reinterpret_cast<sfrag*>(yb + (size_t)q * a.C + v) = h;
         }
       }
     } else {
-      quad rr[MF][NF];
+      squad rr[MF][NF];
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
         const int v = cb + m * 4;
@@ -693,7 +710,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
           const bool ok = v < a.C && q < Tb && !QVC_ABL(3);
-          rr[m][n] = *reinterpret_cast<const quad*>(xres + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0));
+          rr[m][n] = *reinterpret_cast<const squad*>(xres + (size_t)(ok ? q : 0) * a.C + (ok ? v : 0));
         }
       }
 #pragma unroll
@@ -704,11 +721,11 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         for (int n = 0; n < NF; ++n) {
           const int q = qw + n * 16;
           if (q >= Tb) continue;
-          const quad r4 = rr[m][n];
-          quad h;
-          h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r4[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r4[1]);
-          h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r4[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r4[3]);
-          *reinterpret_cast<quad*>(yb + (size_t)q * a.C + v) = h;
+          const squad r4 = rr[m][n];
+          squad h;
+          h[0] = OS::cvt(acc[m][n][0] + bias[m].x + (float)r4[0]); h[1] = OS::cvt(acc[m][n][1] + bias[m].y + (float)r4[1]);
+          h[2] = OS::cvt(acc[m][n][2] + bias[m].z + (float)r4[2]); h[3] = OS::cvt(acc[m][n][3] + bias[m].w + (float)r4[3]);
+          *reinterpret_cast<squad*>(yb + (size_t)q * a.C + v) = h;
         }
       }
     }
@@ -802,7 +819,7 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
       if (idx < total) {
         const int ti = t_base + r;
         uint4 raw = pf[u];
-        if (ti < 0 || ti >= T_ || c8 * 8 >= C) raw = make_uint4(0u, 0u, 0u, 0u);
+        if (ti < ragged_lo(A.rg, b) || ti >= T_ || c8 * 8 >= C) raw = make_uint4(0u, 0u, 0u, 0u);
         frag h; __builtin_memcpy(&h, &raw, 16);
         *reinterpret_cast<frag*>(tileb + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = lrelu8<T>(h, a.slope);
         const int rr = r - h1 - h2;                    // tile row of frame q0 is h1 + h2
@@ -842,7 +859,7 @@ __global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 
       for (int n = 0; n < NF1; ++n) {
         const int jr = n * 16 + lrow;                  // intermediate row <-> frame q0 - h2 + jr
         const int f = q0 - h2 + jr;
-        const bool inside = f >= 0 && f < T_;          // conv2 zero-pads outside [0, T)
+        const bool inside = f >= ragged_lo(A.rg, b) && f < T_;   // conv2 zero-pads outside the utterance
         char* rowp = tileb + jr * rowbytes;
         const int sw = swz(jr, sm);
         if constexpr (kWide) {
@@ -968,7 +985,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
   const Swz sm = swz_mode(cpr);
   char* acts = smem + R * rowbytes;                              // second tile: NT rows of gated activations
   const float* xb = a.x_in + (size_t)b * a.bs;
-  const int Tb = ragged_len(a.rg, b, a.T);
+  const int Tb = ragged_len(a.rg, b, a.T), Tlo = ragged_lo(a.rg, b);
   if (q0 >= Tb) return;
 
   if (!QVC_ABL(0)) {   // ---- stage x (fp32 -> operand type), rows [q0-left, q0-left+R)
@@ -982,7 +999,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
         const int idx = base + u * NTH;
         const int r = idx / cpr, c8 = idx - r * cpr;
         const int ti = q0 - left + r;
-        const bool ok = idx < total && ti >= 0 && ti < Tb && (c8 * 8 < a.H);
+        const bool ok = idx < total && ti >= Tlo && ti < Tb && (c8 * 8 < a.H);
         v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
         if (ok) {
           const float4* p = reinterpret_cast<const float4*>(xb + (size_t)ti * a.H + c8 * 8);
@@ -1111,7 +1128,8 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * kWnOutFrames;
-  const int Tb = ragged_len(a.rg, b, a.T);    // this utterance's length: x is zero outside [0, Tb) at every layer
+  const int Tb = ragged_len(a.rg, b, a.T);    // this utterance occupies rows [Tlo, Tb): x is zero outside at every layer
+  const int Tlo = ragged_lo(a.rg, b);
   if (q0 >= Tb) return;
   const int left = (a.taps - 1) / 2;
   const int halo = left * a.layers;
@@ -1137,7 +1155,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
     for (int idx = tid; idx < NB * pcpr; idx += NTH) {
       const int r = idx / pcpr, c8 = idx - r * pcpr;
       const int q = w0 + r;
-      if (q >= 0 && q < Tb && c8 * 8 < a.pre_cin) {
+      if (q >= Tlo && q < Tb && c8 * 8 < a.pre_cin) {
         const float4* p = reinterpret_cast<const float4*>(zb + (size_t)q * a.z_ts + c8 * 8);
         const float4 v0 = p[0], v1 = p[1];
         frag h;
@@ -1162,7 +1180,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const int q = w0 + n * 16 + lrow;
-        const bool in = ch0 < a.H && q >= 0 && q < Tb;
+        const bool in = ch0 < a.H && q >= Tlo && q < Tb;
         xr[f][n] = in ? f32x4{pacc[f][n][0] + bp.x, pacc[f][n][1] + bp.y, pacc[f][n][2] + bp.z, pacc[f][n][3] + bp.w}
                       : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -1176,7 +1194,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       const int q = w0 + n * 16 + lrow;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!a.w_pre) {
-        if (ch0 < a.H && q >= 0 && q < Tb) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
+        if (ch0 < a.H && q >= Tlo && q < Tb) v = *reinterpret_cast<const float4*>(a.x0 + (size_t)b * a.bs + (size_t)q * a.H + ch0);
         xr[f][n] = f32x4{v.x, v.y, v.z, v.w};
       }
       if (n >= OLO && n < OLO + ON) {
@@ -1261,7 +1279,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
           for (int n = 0; n < NF; ++n) {
             const int q = w0 + n * 16 + lrow;
-            const bool in = q >= 0 && q < Tb;                  // the convs zero-pad x outside the utterance
+            const bool in = q >= Tlo && q < Tb;                  // the convs zero-pad x outside the utterance
             xr[f][n][0] = in ? xr[f][n][0] + acc[f][n][0] + b0.x : 0.f;
             xr[f][n][1] = in ? xr[f][n][1] + acc[f][n][1] + b0.y : 0.f;
             xr[f][n][2] = in ? xr[f][n][2] + acc[f][n][2] + b0.z : 0.f;
@@ -1487,9 +1505,9 @@ inline TileChoice choose_pair_tile(const ConvDesc* ds, int n, int T, int batch) 
   return best;
 }
 
-template <typename T, int MF, int NF, int WM, int NWV>
+template <typename T, int MF, int NF, int WM, int NWV, typename TS>
 inline int launch_pair_one(const PairArgs3& a, int batch, size_t lds, hipStream_t stream) {
-  auto kern = rbpair_kernel<T, MF, NF, WM, NWV>;
+  auto kern = rbpair_kernel<T, MF, NF, WM, NWV, TS>;
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   constexpr int NT = (NWV / WM) * NF * 16;
@@ -1497,16 +1515,16 @@ inline int launch_pair_one(const PairArgs3& a, int batch, size_t lds, hipStream_
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
-template <typename T, int MF, int WM, int NWV>
+template <typename T, int MF, int WM, int NWV, typename TS>
 inline int launch_pair_nf(const ConvDesc* ds, const PairArgs3& a, int batch, hipStream_t stream, int* nf_out) {
   const TileChoice tc = choose_pair_tile(ds, a.n, a.p[0].T, batch);
   if (nf_out) *nf_out = tc.NF;
   switch (tc.NF) {
-    case 2: return launch_pair_one<T, MF, 2, WM, NWV>(a, batch, tc.lds, stream);
-    case 4: return launch_pair_one<T, MF, 4, WM, NWV>(a, batch, tc.lds, stream);
-    case 5: return launch_pair_one<T, MF, 5, WM, NWV>(a, batch, tc.lds, stream);
-    case 8: if constexpr (MF * 9 * 4 <= 160) return launch_pair_one<T, MF, 8, WM, NWV>(a, batch, tc.lds, stream); break;
-    case 10: if constexpr (MF * 11 * 4 <= 96) return launch_pair_one<T, MF, 10, WM, NWV>(a, batch, tc.lds, stream); break;
+    case 2: return launch_pair_one<T, MF, 2, WM, NWV, TS>(a, batch, tc.lds, stream);
+    case 4: return launch_pair_one<T, MF, 4, WM, NWV, TS>(a, batch, tc.lds, stream);
+    case 5: return launch_pair_one<T, MF, 5, WM, NWV, TS>(a, batch, tc.lds, stream);
+    case 8: if constexpr (MF * 9 * 4 <= 160) return launch_pair_one<T, MF, 8, WM, NWV, TS>(a, batch, tc.lds, stream); break;
+    case 10: if constexpr (MF * 11 * 4 <= 96) return launch_pair_one<T, MF, 10, WM, NWV, TS>(a, batch, tc.lds, stream); break;
     default: break;
   }
   return QVC_ERR_BAD_CONFIG;
@@ -1559,11 +1577,11 @@ inline int launch_pair_persist(const ConvDesc* ds, const PairArgs3& a, int batch
 }
 
 
-template <typename T>
+template <typename T, typename TS>
 int launch_pair_typed(const ConvDesc* ds, const PairArgs3& a, int batch, void* stream_v, int* nf_out) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const ConvDesc& d = ds[0];
-  if (d.WM == 4 && pair_persist_mode() != 0) {
+  if (d.WM == 4 && pair_persist_mode() != 0 && std::is_same<T, TS>::value) {
     bool taken = false;
     int st = QVC_OK;
     if (d.MF == 2) st = launch_pair_persist<T, 2, 10>(ds, a, batch, stream, &taken);
@@ -1571,16 +1589,16 @@ int launch_pair_typed(const ConvDesc* ds, const PairArgs3& a, int batch, void* s
     if (taken || st != QVC_OK) { if (nf_out) *nf_out = 110; return st; }
   }
   switch (d.WM * 10 + d.MF) {
-    case 41: return launch_pair_nf<T, 1, 4, 4>(ds, a, batch, stream, nf_out);
-    case 42: return launch_pair_nf<T, 2, 4, 4>(ds, a, batch, stream, nf_out);
-    case 43: return launch_pair_nf<T, 3, 4, 4>(ds, a, batch, stream, nf_out);
-    case 44: return launch_pair_nf<T, 4, 4, 4>(ds, a, batch, stream, nf_out);
-    case 23: return launch_pair_nf<T, 3, 2, 4>(ds, a, batch, stream, nf_out);
-    case 24: return launch_pair_nf<T, 4, 2, 4>(ds, a, batch, stream, nf_out);
-    case 14: return launch_pair_nf<T, 4, 1, 4>(ds, a, batch, stream, nf_out);
-    case 82: return launch_pair_nf<T, 2, 8, 8>(ds, a, batch, stream, nf_out);
-    case 83: return launch_pair_nf<T, 3, 8, 8>(ds, a, batch, stream, nf_out);
-    case 84: return launch_pair_nf<T, 4, 8, 8>(ds, a, batch, stream, nf_out);
+    case 41: return launch_pair_nf<T, 1, 4, 4, TS>(ds, a, batch, stream, nf_out);
+    case 42: return launch_pair_nf<T, 2, 4, 4, TS>(ds, a, batch, stream, nf_out);
+    case 43: return launch_pair_nf<T, 3, 4, 4, TS>(ds, a, batch, stream, nf_out);
+    case 44: return launch_pair_nf<T, 4, 4, 4, TS>(ds, a, batch, stream, nf_out);
+    case 23: return launch_pair_nf<T, 3, 2, 4, TS>(ds, a, batch, stream, nf_out);
+    case 24: return launch_pair_nf<T, 4, 2, 4, TS>(ds, a, batch, stream, nf_out);
+    case 14: return launch_pair_nf<T, 4, 1, 4, TS>(ds, a, batch, stream, nf_out);
+    case 82: return launch_pair_nf<T, 2, 8, 8, TS>(ds, a, batch, stream, nf_out);
+    case 83: return launch_pair_nf<T, 3, 8, 8, TS>(ds, a, batch, stream, nf_out);
+    case 84: return launch_pair_nf<T, 4, 8, 8, TS>(ds, a, batch, stream, nf_out);
     default: return QVC_ERR_BAD_CONFIG;
   }
 }

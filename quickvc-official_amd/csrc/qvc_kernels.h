@@ -11,14 +11,18 @@ enum XKind : int32_t {
   XK_F32_CM = 2    // fp32, channel-major (B, C, T) -- the reference's external layout
 };
 
-// Ragged batches (utterances of different lengths padded to one shape): utterance b has lens[b] unit frames, and a
-// launch that works at `mul` frames per unit frame (+ add) treats it as  min(T, lens[b] * mul + add)  frames long.
-// Every conv zero-pads at the end of ITS sequence (not of the padded buffer), so the staging code masks rows by
-// this length; rows past it are never read unmasked, which is why nothing has to be zeroed between launches.
-// lens == nullptr: all utterances are T frames long.  lens lives wherever the launch's other pointers live.
+// Ragged batches and streaming windows: where does utterance b start and end inside the buffer a launch works on?
+// Buffer row r (at `mul` rows per unit frame) of utterance b is absolute frame  (pos[b] - off) * mul + r  of its
+// sequence, which is lens[b] * mul + add frames long.  Every conv zero-pads at the two ends of ITS sequence -- not of
+// the padded buffer, not of a streaming window -- so the staging code masks rows outside [lo, hi):
+//     lo = max(0, (off - pos[b]) * mul)          hi = min(T, (lens[b] - pos[b] + off) * mul + add)
+// Rows outside are never read unmasked, which is why nothing has to be zeroed between launches.
+//   lens == nullptr: the sequence ends with the buffer (hi = T);  pos == nullptr: it starts with it (pos = off = 0).
+// The arrays live wherever the launch's other pointers live (device memory; host memory in the CPU emulation).
 struct Ragged {
   const int32_t* lens = nullptr;
-  int32_t mul = 1, add = 0;
+  const int32_t* pos = nullptr;
+  int32_t mul = 1, add = 0, off = 0;
 };
 #if defined(__HIPCC__)
 #define QVC_HD __host__ __device__ __forceinline__
@@ -27,10 +31,15 @@ struct Ragged {
 #endif
 // (by value and always inlined: a reference to a member of the by-value kernel arguments would make the compiler
 //  copy the whole argument struct to scratch memory -- measured: 296 B of scratch and half the occupancy)
-QVC_HD int ragged_len(const Ragged r, int b, int T) {
+QVC_HD int ragged_len(const Ragged r, int b, int T) {          // hi
   if (!r.lens) return T;
-  const int n = r.lens[b] * r.mul + r.add;
+  const int n = (r.lens[b] - (r.pos ? r.pos[b] - r.off : 0)) * r.mul + r.add;
   return n < 0 ? 0 : (n < T ? n : T);
+}
+QVC_HD int ragged_lo(const Ragged r, int b) {                  // lo
+  if (!r.pos) return 0;
+  const int n = (r.off - r.pos[b]) * r.mul;
+  return n < 0 ? 0 : n;
 }
 
 // Arguments of one implicit-GEMM conv launch.  All strides in elements.
@@ -184,6 +193,6 @@ int launch_tail(const TailArgs& a, void* stream);
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
 template <typename T> int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream);
 template <typename T> int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream, int* nf_out);
-template <typename T> int launch_pair_typed(const ConvDesc* d1, const PairArgs3& a, int batch, void* stream, int* nf_out);
+template <typename T, typename TS> int launch_pair_typed(const ConvDesc* d1, const PairArgs3& a, int batch, void* stream, int* nf_out);   // TS: stream type
 
 }  // namespace qvc

@@ -259,8 +259,12 @@ extern "C" int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors
     for (int j = 0; j < cfg->n_resblocks; ++j)
       for (int q = 0; q < 3; ++q) {
         const std::string rb = "dec.resblocks." + std::to_string(i * cfg->n_resblocks + j);
+        // fused pairs take their own operand type (bf16 in the mixed mode); the unfused fallback runs as generator convs
+        const bool fusedp = pair_supported(st.c1[(size_t)j * 3 + q], st.c2[(size_t)j * 3 + q]) && st.c1[(size_t)j * 3 + q].lp;
+        pk.cur_dtype = fusedp ? pair_weight_dtype(*cfg) : dec_dtype(*cfg);
         pk.pack_conv1d(st.c1[(size_t)j * 3 + q], rb + ".convs1." + std::to_string(q));
         pk.pack_conv1d(st.c2[(size_t)j * 3 + q], rb + ".convs2." + std::to_string(q));
+        pk.cur_dtype = dec_dtype(*cfg);
       }
   }
   if (pk.status == QVC_OK) pk.pack_conv1d(P.conv_post, "dec.subband_conv_post");

@@ -29,13 +29,19 @@ struct Path {
   int B, T;
   Backend& be;
   int status = QVC_OK;
-  // ragged batch: per-utterance unit-frame counts (nullptr: every utterance is T frames long); see Ragged
+  // ragged batches / streaming windows (see Ragged): per-utterance sequence lengths, and -- for a window that is not
+  // the whole sequence -- the absolute unit frame `pos[b]` that sits at buffer row `off`
   const int32_t* lens = nullptr;
-  Ragged rg(int mul, int add = 0) const { Ragged r; r.lens = lens; r.mul = mul; r.add = add; return r; }
+  const int32_t* pos = nullptr;
+  int32_t off = 0;
+  Ragged rg(int mul, int add = 0) const { Ragged r; r.lens = lens; r.pos = pos; r.mul = mul; r.add = add; r.off = off; return r; }
+  // streaming: stage-0 ResBlock outputs handed over from a previous window instead of this call's own (dec_back)
+  const void* s0_override[3] = {nullptr, nullptr, nullptr};
 
   template <typename U> U* wsp(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
   int dtype_wn() const { return wn_dtype(P.cfg); }     // enc_p / enc_q / flow
-  int dtype_dec() const { return dec_dtype(P.cfg); }   // generator
+  int dtype_dec() const { return dec_dtype(P.cfg); }   // generator convs
+  int dtype_pair() const { return pair_dtype(P.cfg); } // fused ResBlock pairs (may differ: QVC_BF16X)
 
   ConvArgs args(const ConvDesc& d, const char* wb = nullptr) const {
     ConvArgs a;
@@ -223,16 +229,23 @@ struct Path {
   void mean_input(ConvArgs& a, size_t i) {
     const int NB = P.cfg.n_resblocks;
     a.x_kind = XK_OP_FM;
-    a.x = wsp<void>(W.ra[i][0]);
-    a.x2 = wsp<void>(W.ra[i][(size_t)(NB > 1 ? 1 : 0)]);
-    a.x3 = wsp<void>(W.ra[i][(size_t)(NB > 2 ? 2 : 0)]);
+    auto src = [&](int j) -> const void* { return (i == 0 && s0_override[j]) ? s0_override[j] : wsp<void>(W.ra[i][(size_t)j]); };
+    a.x = src(0);
+    a.x2 = src(NB > 1 ? 1 : 0);
+    a.x3 = src(NB > 2 ? 2 : 0);
   }
 
-  // ---- generator trunk (models.py:372-390)
+  // ---- generator trunk (models.py:372-390).  dec_front = conv_pre + stage 0 (its three ResBlock outputs end up in
+  // W.ra[0][j]); dec_back = the remaining stages + conv_post, reading stage 0's outputs (or s0_override: streaming).
   void dec_trunk(const float* z, float* post_out) {
+    dec_part(z, post_out, 0, (int)P.stages.size(), true, true);
+  }
+  void dec_front(const float* z) { dec_part(z, nullptr, 0, 1, true, false); }
+  void dec_back(float* post_out) { dec_part(nullptr, post_out, 1, (int)P.stages.size(), false, true); }
+  void dec_part(const float* z, float* post_out, int stage_lo, int stage_hi, bool with_pre, bool with_post) {
     const qvc_config& c = P.cfg;
     const int C = c.inter_channels, C0 = c.upsample_initial_channel;
-    {   // conv_pre(k7) + cond(g), then the first stage's leaky ReLU fused into the store
+    if (with_pre) {   // conv_pre(k7) + cond(g), then the first stage's leaky ReLU fused into the store
       ConvArgs a = args(P.conv_pre);
       a.x = z; a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * C; a.x_ts = C; a.T_in = T;
       a.Nq = T; a.T_out = T; a.rg = rg(1);
@@ -242,7 +255,12 @@ struct Path {
     }
     int t_in = T, ch_in = C0;
     int rate = 1;                                    // frames per unit frame at the current stage's INPUT
-    for (size_t i = 0; i < P.stages.size(); ++i) {
+    for (size_t i = 0; i < (size_t)stage_hi; ++i) {
+      if ((int)i < stage_lo) {                       // geometry of the stages this call skips
+        const int s_ = P.stages[i].up.up_s, p_ = P.stages[i].up.up_p, k_ = c.upsample_kernel_sizes[i];
+        t_in = (t_in - 1) * s_ - 2 * p_ + k_ + (1 - (int)i); ch_in = P.stages[i].ch; rate *= s_;
+        continue;
+      }
       const StagePlan& st = P.stages[i];
       const int s = st.up.up_s, p = st.up.up_p, k = c.upsample_kernel_sizes[i];
       const int t_out = (t_in - 1) * s - 2 * p + k + (1 - (int)i);         // models.py:335
@@ -301,7 +319,7 @@ struct Path {
             d1s[s_] = st.c1[(size_t)j * 3 + q]; d2s[s_] = st.c2[(size_t)j * 3 + q];
             src[(size_t)j] = dst;
           }
-          if (status == QVC_OK) status = be.pair3(d1s, d2s, a3, B, dtype_dec());
+          if (status == QVC_OK) status = be.pair3(d1s, d2s, a3, B, dtype_pair());
         }
       } else {
       be.fork(NB);                                   // branches wait for everything enqueued so far
@@ -315,7 +333,7 @@ struct Path {
           if (pair_supported(d1, d2) && d1.lp && d2.lp) {
             PairArgs3 a1; a1.n = 1; a1.rg = rg(rate);
             a1.p[0] = pair_args(j, q, dst);
-            if (status == QVC_OK) status = be.pair3(&d1, &d2, a1, B, dtype_dec());
+            if (status == QVC_OK) status = be.pair3(&d1, &d2, a1, B, dtype_pair());
           } else {
             void* xt = wsp<char>(W.xt[i]) + (size_t)j * (size_t)B * (size_t)bs * 2;
             {   // lrelu -> dilated conv -> lrelu (stored already activated)
@@ -341,7 +359,7 @@ struct Path {
       }
       t_in = t_out; ch_in = ch;
     }
-    {   // lrelu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post(k7)
+    if (with_post) {   // lrelu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post(k7)
       ConvArgs a = args(P.conv_post);
       mean_input(a, P.stages.size() - 1);
       a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in;

@@ -17,9 +17,12 @@ constexpr int kWaves = 4;          // waves per workgroup in the conv kernel (M 
 constexpr int kKStep = 32;         // MFMA 16x16x32: K elements per step
 constexpr int kFragElems = 512;    // one A fragment = 64 lanes x 8 elements
 
-// operand type of the two halves of the path (QVC_BF16X: bf16 WaveNets, f16 generator; they meet at fp32 tensors)
-inline int wn_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_BF16 : c.operand_dtype; }
-inline int dec_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_F16 : c.operand_dtype; }
+// Operand types by part of the path.  QVC_BF16X = bf16 MFMA operands in the ResBlock pairs (80 % of the path's
+// FLOPs) with their residual stream kept in f16, f16 everywhere else (WaveNets, conv_pre, up-samplers, conv_post).
+inline int wn_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_F16 : c.operand_dtype; }    // enc_p / enc_q / flow
+inline int dec_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_F16 : c.operand_dtype; }   // generator convs + streams
+inline int pair_dtype(const qvc_config& c) { return c.operand_dtype; }                 // launch code of the pairs (QVC_BF16X itself)
+inline int pair_weight_dtype(const qvc_config& c) { return c.operand_dtype == QVC_BF16X ? QVC_BF16 : c.operand_dtype; }
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   const int a0 = o0 >> 2;                   // first band sample owned by this block
   const int f_lo = (o0 >> 4) - 3;           // first frame staged
   const int Lpad = 4 * (a.F - 1);           // band signal length of the (padded) buffers
-  const int Fb = ragged_len(a.rg, b, a.F);  // this utterance's frame count (ragged batches): its iSTFT envelope ends there
-  const int L = Fb > 0 ? 4 * (Fb - 1) : 0;  // band signal length of this utterance; samples past it are zeros
+  const int Fb = ragged_len(a.rg, b, a.F);  // this utterance's frames are [Flo, Fb) of the buffer (ragged batches,
+  const int Flo = ragged_lo(a.rg, b);       // streaming windows): its iSTFT envelope starts / ends there
+  const int L = Fb > 0 ? 4 * (Fb - 1) : 0;  // its band signal is [4*Flo, L); samples outside are zeros
   const float* pb = a.post + (size_t)b * a.F * kPostC;
 
   // ---- stage frames [f_lo, f_lo+kNFR) x 72 channels (contiguous in memory), float4 coalesced
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
       const int fr = i / (kPostC / 4), c4 = i - fr * (kPostC / 4);
       const int t = f_lo + fr;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < kChunks && t >= 0 && t < Fb) v[u] = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
+      if (i < kChunks && t >= Flo && t < Fb) v[u] = *reinterpret_cast<const float4*>(pb + (size_t)t * kPostC + c4 * 4);
     }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
     const int k = item / kNY, i = item - k * kNY;
     const int n = a0 - 7 + i;
     float y = 0.f;
-    if (n >= 0 && n < L) {
+    if (n >= 4 * Flo && n < L) {
       constexpr float C16b[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
                                   -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
                                   -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.f,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int t = t_hi - d, m = n + 8 - 4 * t;
-        if (t >= 0 && t < Fb && m < 16) {
+        if (t >= Flo && t < Fb && m < 16) {
           const float w = 0.5f - 0.5f * C16b[m];
           num += s_xw[k][t - f_lo][m];
           env += w * w;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
     }
     const int o = o0 + 4 * tid;
     const int n_out = 4 * Lpad;
-    if (o >= 4 * L) out[0] = out[1] = out[2] = out[3] = 0.f;     // past this utterance's end (4*L is a multiple of 4)
+    if (o >= 4 * L || o < 16 * Flo) out[0] = out[1] = out[2] = out[3] = 0.f;   // outside this utterance (both bounds are multiples of 4)
     if (o + 3 < n_out) {
       *reinterpret_cast<float4*>(a.out + (size_t)b * n_out + o) = make_float4(out[0], out[1], out[2], out[3]);
     } else {
@@ -311,8 +312,9 @@ int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int
     if (d1[i].MF != d1[0].MF || d1[i].WM != d1[0].WM || d1[i].CinP != d1[0].CinP) return QVC_ERR_BAD_CONFIG;
     if (a.p[i].T != a.p[0].T || a.p[i].C != a.p[0].C || a.p[i].CP != a.p[0].CP) return QVC_ERR_BAD_ARG;
   }
-  if (dtype == QVC_F16) return launch_pair_typed<_Float16>(d1, a, batch, stream, nf_out);
-  if (dtype == QVC_BF16) return launch_pair_typed<__bf16>(d1, a, batch, stream, nf_out);
+  if (dtype == QVC_F16) return launch_pair_typed<_Float16, _Float16>(d1, a, batch, stream, nf_out);
+  if (dtype == QVC_BF16) return launch_pair_typed<__bf16, __bf16>(d1, a, batch, stream, nf_out);
+  if (dtype == QVC_BF16X) return launch_pair_typed<__bf16, _Float16>(d1, a, batch, stream, nf_out);   // bf16 operands, f16 stream
   return QVC_ERR_BAD_ARG;
 }
 

@@ -16,6 +16,10 @@ import torch
 from . import lib as L
 
 
+def aligned_empty(nbytes: int, device) -> torch.Tensor:
+    return _aligned_empty(nbytes, device)
+
+
 def _aligned_empty(nbytes: int, device) -> torch.Tensor:
     raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
     shift = (-raw.data_ptr()) % 256
@@ -148,6 +152,29 @@ class QvcEngine:
                                              torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib, st, "qvc_infer_batch_ragged")
         return out
+
+    # ---- streaming (qvc_stream_step): sizes, lags and one step; the state / workspace tensors belong to the caller
+    def stream_sizes(self, batch: int, hop: int):
+        """(state_bytes, workspace_bytes, lag_frames, noise_lag_frames) for `batch` streams fed `hop` frames per step."""
+        vals = (int(self.lib.qvc_stream_state_bytes(ctypes.byref(self.cfg), batch, hop)),
+                int(self.lib.qvc_stream_workspace_bytes(ctypes.byref(self.cfg), batch, hop)),
+                int(self.lib.qvc_stream_lag_frames(ctypes.byref(self.cfg))),
+                int(self.lib.qvc_stream_noise_lag_frames(ctypes.byref(self.cfg))))
+        for v in vals:
+            if v < 0:
+                L.check(self.lib, v, "qvc_stream_*_bytes")
+        return vals
+
+    @_on_device
+    def stream_step(self, state: torch.Tensor, ws: torch.Tensor, unit_new: torch.Tensor, g: torch.Tensor, noise_new: torch.Tensor,
+                    out: torch.Tensor, pos: torch.Tensor, lens: torch.Tensor) -> None:
+        """One hop for every stream (all tensors fp32 / int32, contiguous, on this device; see include/qvc.h)."""
+        B, _, hop = unit_new.shape
+        st = self.lib.qvc_stream_step(ctypes.byref(self.cfg), self.blob.data_ptr(), state.data_ptr(), state.numel(),
+                                      unit_new.data_ptr(), g.data_ptr(), noise_new.data_ptr(), out.data_ptr(), B, hop,
+                                      pos.data_ptr(), lens.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_stream_step")
 
     @_on_device
     def speaker_embed(self, mel: torch.Tensor) -> torch.Tensor:

@@ -69,6 +69,16 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_infer_batch.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
         lib.qvc_infer_batch_ragged.restype = ctypes.c_int
         lib.qvc_infer_batch_ragged.argtypes = [cfgp, V, V, V, V, V, I, I, V, V, L, V]
+        lib.qvc_stream_state_bytes.restype = L
+        lib.qvc_stream_state_bytes.argtypes = [cfgp, I, I]
+        lib.qvc_stream_workspace_bytes.restype = L
+        lib.qvc_stream_workspace_bytes.argtypes = [cfgp, I, I]
+        lib.qvc_stream_lag_frames.restype = I
+        lib.qvc_stream_lag_frames.argtypes = [cfgp]
+        lib.qvc_stream_noise_lag_frames.restype = I
+        lib.qvc_stream_noise_lag_frames.argtypes = [cfgp]
+        lib.qvc_stream_step.restype = ctypes.c_int
+        lib.qvc_stream_step.argtypes = [cfgp, V, V, L, V, V, V, V, I, I, V, V, V, L, V]
         lib.qvc_aux_create.restype = ctypes.c_int
         lib.qvc_aux_create.argtypes = [P(V)]
         lib.qvc_aux_destroy.restype = ctypes.c_int
@@ -131,7 +141,7 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 6:
+        if lib.qvc_abi_version() != 7:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -87,3 +87,109 @@ class ChunkedConverter:
                 out[:, :, t0 * self.spf:(t0 + n) * self.spf].copy_(self._out[:, :, lo:lo + n * self.spf])
             self._stream.synchronize()
         return out
+
+
+class StreamConverter:
+    """Incremental conversion of ``streams`` concurrent streams, ``hop_frames`` new unit frames per step
+    (qvc_stream_step; BASELINE.json configs[4]).  Unlike ChunkedConverter it needs nothing but the frames seen so
+    far: the state (ring buffers at five points of the path, csrc/qvc_stream.h) lives in a tensor owned by this
+    object, every step is ONE replay of a captured hipGraph (fixed shapes; the stream position is a device
+    counter the graph itself advances), and a frame costs about (2*H + hop)/hop of its offline cost per segment
+    instead of (2*88 + hop)/hop.  Output lags the input by ``self.lag`` frames -- the look-ahead the non-causal
+    network needs; it is exact, including the first and last frames of a stream."""
+
+    def __init__(self, model, streams: int, hop_frames: int = 320, use_graph: bool = True):
+        from .engine import aligned_empty
+        self.model, self.streams, self.hop = model, int(streams), int(hop_frames)
+        self.engine = model.engine()
+        dev = self.engine.device
+        mc = model.model_config
+        n_state, n_ws, self.lag, self.noise_lag = self.engine.stream_sizes(self.streams, self.hop)
+        self.spf = model.samples_per_frame
+        self._state = aligned_empty(n_state, dev)
+        self._ws = aligned_empty(n_ws, dev)
+        S, h = self.streams, self.hop
+        self._unit = torch.zeros(S, mc.get("unit_channels", 256), h, device=dev)
+        self._noise = torch.zeros(S, mc["inter_channels"], h, device=dev)
+        self._g = torch.zeros(S, mc["gin_channels"], device=dev)
+        self._out = torch.zeros(S, h * self.spf, device=dev)
+        self._pos = torch.zeros(S, dtype=torch.int32, device=dev)
+        self._len = torch.full((S,), 2 ** 30, dtype=torch.int32, device=dev)
+        self._stream = torch.cuda.Stream(dev)
+        self._graph = None
+        self.reset()
+        if use_graph:
+            with torch.cuda.stream(self._stream):
+                self._one_step()                                  # warm-up (code objects)
+                self._stream.synchronize()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph, stream=self._stream):
+                    self._one_step()
+            self.reset()
+
+    def _one_step(self):
+        self.engine.stream_step(self._state, self._ws, self._unit, self._g, self._noise, self._out, self._pos, self._len)
+        self._pos.add_(self.hop)                                 # inside the graph: the position advances with every replay
+
+    def reset(self, g: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None) -> None:
+        """Start new streams: zero state, position 0; ``g`` (S, gin) speaker embeddings; ``lengths`` (S,) if known."""
+        with torch.cuda.stream(self._stream):
+            self._state.zero_()
+            self._pos.zero_()
+            self._len.fill_(2 ** 30)
+            if g is not None:
+                self._g.copy_(g.reshape(self.streams, -1))
+            if lengths is not None:
+                self._len.copy_(torch.as_tensor(lengths, dtype=torch.int32))
+        self._stream.synchronize()
+
+    def end(self, lengths) -> None:
+        """Tell the converter where the streams end (frames); keep stepping until ``position - lag >= length`` to flush."""
+        with torch.cuda.stream(self._stream):
+            self._len.copy_(torch.as_tensor(lengths, dtype=torch.int32))
+
+    @torch.no_grad()
+    def step(self, unit_new: torch.Tensor, noise_new: torch.Tensor) -> torch.Tensor:
+        """Feed frames [pos, pos+hop) of every stream (unit_new (S, 256, hop)) and the noise for frames
+        [pos - noise_lag, ... + hop) (noise_new (S, inter, hop)); returns the waveform of frames
+        [pos - lag, pos - lag + hop) as (S, hop * samples_per_frame) -- zeros where that lies outside the stream."""
+        dev = self.engine.device
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._stream):
+            self._unit.copy_(unit_new, non_blocking=True)
+            self._noise.copy_(noise_new, non_blocking=True)
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._one_step()
+            out = self._out.clone()
+        torch.cuda.current_stream(dev).wait_stream(self._stream)
+        return out
+
+    @torch.no_grad()
+    def convert(self, unit: torch.Tensor, g: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Convenience: stream whole utterances through the step interface.  unit (S, 256, T), g (S, gin),
+        noise (S, inter, T) -> (S, 1, T * samples_per_frame); equals infer_batch on the whole thing."""
+        S, UC, T = unit.shape
+        if S != self.streams:
+            raise ValueError(f"built for {self.streams} streams, got {S}")
+        dev = self.engine.device
+        inter = self.model.model_config["inter_channels"]
+        if noise is None:
+            noise = torch.randn(S, inter, T, device=dev)
+        unit, noise = unit.to(dev, torch.float32), noise.to(dev, torch.float32)
+        h, lag, nl, spf = self.hop, self.lag, self.noise_lag, self.spf
+        self.reset(g.to(dev, torch.float32), torch.full((S,), T, dtype=torch.int32))
+        out = torch.zeros(S, 1, T * spf, device=dev)
+        pad_u = torch.nn.functional.pad(unit, (0, h + lag))                      # frames past the end: ignored by the kernels
+        pad_n = torch.nn.functional.pad(noise, (nl, h + lag))                    # frame f of the noise sits at column f + nl
+        steps = -(-(T + lag) // h)
+        for n in range(steps):
+            s = n * h
+            chunk = self.step(pad_u[:, :, s:s + h], pad_n[:, :, s:s + h])         # noise frames [s - nl, s - nl + h)
+            f0 = s - lag
+            lo, hi = max(f0, 0), min(f0 + h, T)
+            if hi > lo:
+                out[:, 0, lo * spf:hi * spf] = chunk[:, (lo - f0) * spf:(hi - f0) * spf]
+        torch.cuda.synchronize(dev)
+        return out

@@ -20,6 +20,8 @@ def load_emu():
     lib.qvc_emu_infer_batch.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, Lg]
     lib.qvc_emu_infer_batch_ragged.restype = ctypes.c_int
     lib.qvc_emu_infer_batch_ragged.argtypes = [P(L.QvcConfig), V, V, V, V, V, I, I, V, V, Lg]
+    lib.qvc_emu_stream_step.restype = ctypes.c_int
+    lib.qvc_emu_stream_step.argtypes = [P(L.QvcConfig), V, V, Lg, V, V, V, V, I, I, V, V, V, Lg]
     lib.qvc_emu_speaker_embed.restype = ctypes.c_int
     lib.qvc_emu_speaker_embed.argtypes = [P(L.QvcConfig), V, V, V, I, I, V, Lg]
     lib.qvc_emu_enc_q.restype = ctypes.c_int
@@ -97,6 +99,58 @@ def emu_infer_ragged(model_config, sd, unit, g, noise, frames, dtype="f16"):
                                         out.data_ptr(), B, T, lens.data_ptr(), ws.data_ptr(), n_ws)
     assert st == 0, hip.qvc_status_string(st)
     return out
+
+
+def emu_stream_convert(model_config, sd, unit, g, noise, hop, dtype="f16", lens=None):
+    """Host replay of a whole streamed conversion: feeds `hop` frames per qvc_stream_step until everything (plus the
+    lag) is out.  unit (B, 256, T), noise (B, inter, T); lens: per-stream lengths <= T (default T).  -> (B, 1, T*spf)."""
+    from quickvc_official_amd import lib as L
+    hip = L.load_library()
+    emu = load_emu()
+    mc = dict(model_config, operand_dtype=dtype)
+    cfg = L.make_config(mc)
+    blob = L.pack_weights(hip, cfg, sd)
+    B, UC, T = unit.shape
+    C = mc["inter_channels"]
+    n_state = int(hip.qvc_stream_state_bytes(ctypes.byref(cfg), B, hop))
+    n_ws = int(hip.qvc_stream_workspace_bytes(ctypes.byref(cfg), B, hop))
+    lag, nlag = int(hip.qvc_stream_lag_frames(ctypes.byref(cfg))), int(hip.qvc_stream_noise_lag_frames(ctypes.byref(cfg)))
+    assert n_state > 0 and n_ws > 0 and lag > 0
+
+    def aligned(n):
+        raw = torch.zeros(n + 256, dtype=torch.uint8)
+        shift = (-raw.data_ptr()) % 256
+        return raw, raw[shift:shift + n]
+    _keep1, state = aligned(n_state)
+    _keep2, ws = aligned(n_ws)
+    spf = mc["gen_istft_hop_size"] * mc["subbands"]
+    for u in mc["upsample_rates"]:
+        spf *= u
+    lens_t = torch.as_tensor(lens if lens is not None else [T] * B, dtype=torch.int32).contiguous()
+    out = torch.zeros(B, 1, T * spf)
+    unit, g, noise = unit.float().contiguous(), g.float().contiguous(), noise.float().contiguous()
+    steps = -(-(T + lag) // hop)
+    for n in range(steps):
+        s = n * hop
+        u_new = torch.full((B, UC, hop), 123.0)                       # junk past the end must be ignored
+        n_new = torch.full((B, C, hop), -55.0)
+        lo, hi = s, min(s + hop, T)
+        if hi > lo:
+            u_new[:, :, :hi - lo] = unit[:, :, lo:hi]
+        a, b_ = s - nlag, s - nlag + hop                                # frames enc_p completes in this step
+        lo2, hi2 = max(a, 0), min(b_, T)
+        if hi2 > lo2:
+            n_new[:, :, lo2 - a:hi2 - a] = noise[:, :, lo2:hi2]
+        pos = torch.full((B,), s, dtype=torch.int32)
+        chunk = torch.full((B, hop * spf), float("nan"))
+        st = emu.qvc_emu_stream_step(ctypes.byref(cfg), blob.data_ptr(), state.data_ptr(), n_state, u_new.data_ptr(), g.data_ptr(),
+                                     n_new.data_ptr(), chunk.data_ptr(), B, hop, pos.data_ptr(), lens_t.data_ptr(), ws.data_ptr(), n_ws)
+        assert st == 0, hip.qvc_status_string(st)
+        f0 = s - lag                                                    # the chunk holds frames [f0, f0 + hop)
+        lo3, hi3 = max(f0, 0), min(f0 + hop, T)
+        if hi3 > lo3:
+            out[:, 0, lo3 * spf:hi3 * spf] = chunk[:, (lo3 - f0) * spf:(hi3 - f0) * spf]
+    return out, lag
 
 
 def emu_speaker_embed(model_config, sd, mel, dtype="f16"):

@@ -461,6 +461,31 @@ def test_chunked_streaming_default_noise_is_seeded_like_infer_batch(lib, dev):
     assert snr_db(want.cpu(), got.cpu()) >= 90.0
 
 
+@pytest.mark.parametrize("hop,T", [(320, 960), (16, 250)])
+def test_incremental_streaming_at_stated_size(lib, dev, hop, T):
+    """qvc_stream_step (segment rings, csrc/qvc_stream.h): 64 concurrent streams on the shipped config, 320-frame hop
+    (BASELINE configs[4]) and a 16-frame hop, hipGraph replay per step.  Property at full size: the concatenated
+    step outputs equal the whole-utterance conversion of the same streams (same noise) -- including the first
+    frames, the last frames and the flush -- and a stream that ends early gets zeros after its end."""
+    from quickvc_official_amd.streaming import StreamConverter
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    model, sd, _u, _g, _n = regenerate(entry)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    S = 64
+    unit, g, noise = make_synthetic_inputs(S, T, 256, 192, 256, seed0=6000 + hop)
+    conv = StreamConverter(model, streams=S, hop_frames=hop, use_graph=True)
+    assert conv._graph is not None and conv.lag == 32 + 4 * 8 + 20 + 6 and conv.noise_lag == 32
+    streamed = conv.convert(unit.cuda(), g.cuda(), noise.cuda())
+    whole = model.infer_batch(unit.cuda(), g.cuda(), noise.cuda())
+    torch.cuda.synchronize()
+    assert streamed.shape == whole.shape == (S, 1, 320 * T) and bool(torch.isfinite(streamed).all())
+    worst = min(snr_db(whole[s].cpu(), streamed[s].cpu()) for s in range(0, S, 9))
+    assert worst >= 90.0, worst
+    assert snr_db(whole.cpu(), streamed.cpu()) >= 90.0
+
+
 def test_wide_config_takes_the_fallback_paths(lib, dev):
     """A config the fused pair kernel does not cover: stage-1 ResBlocks 416 channels wide (two M chunks -> the
     conv1 / conv2 launches with an operand-type residual instead of the fused pair); WaveNet width 256 = the

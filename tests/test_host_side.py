@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(ROOT, "include", "qvc.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"\b(qvc_[a-z0-9_]+)\s*\(", header))
-    assert len(names) >= 28
+    assert len(names) >= 33
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 6
+    assert built.qvc_abi_version() == 7
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
 
 
@@ -247,7 +247,7 @@ def test_weight_norm_and_flip_folding_change_nothing(built):
 
 
 @pytest.mark.parametrize("name,dtype,min_db", [("mini", "f16", 50.0), ("odd", "f16", 50.0), ("mini_mb", "f16", 50.0),
-                                               ("mini", "bf16", 32.0)])
+                                               ("mini", "bf16", 32.0), ("mini", "bf16x", 40.0), ("odd", "bf16x", 40.0)])
 def test_host_emulation_of_launch_sequence_matches_oracle(built, name, dtype, min_db):
     """The product's launch sequence + packed blob, replayed on the CPU by oracle/qvc_emu.cpp."""
     from emu import emu_infer
@@ -280,6 +280,26 @@ def test_ragged_batch_host_emulation_matches_per_utterance_oracle(built):
         ref = oracle.infer_from_g(sd, cfg, unit[b:b + 1, :, :n], g[b:b + 1].unsqueeze(-1), noise[b:b + 1, :, :n])
         assert snr_db(ref[0], out[b, :, :320 * n]) >= 45.0, (b, n)
         assert float(out[b, :, 320 * n:].abs().max()) == 0.0 if n < 21 else True      # zeros after the utterance's end
+
+
+def test_streaming_steps_host_emulation_match_whole_utterance(built):
+    """qvc_stream_step replayed on the CPU (odd config: 24 / 40 channels): two streams of lengths 37 and 29 fed 7
+    frames per step through the segment rings, junk in the padding -- the concatenated step outputs must equal
+    the oracle's whole-utterance conversion of each stream (same noise, aligned by the documented lags), including
+    the first frames (sequence start inside a window) and the last ones (end inside a window, then flushing)."""
+    from emu import emu_stream_convert
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("odd")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    cfg = entry["config"]
+    lens = [37, 29]
+    unit, g, noise = make_synthetic_inputs(2, 37, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=90)
+    out, lag = emu_stream_convert(cfg, sd, unit, g, noise, hop=7, dtype="f16", lens=lens)
+    assert lag == 32 + 4 * 8 + 20 + 6
+    for b, n in enumerate(lens):
+        ref = oracle.infer_from_g(sd, cfg, unit[b:b + 1, :, :n], g[b:b + 1].unsqueeze(-1), noise[b:b + 1, :, :n])
+        assert snr_db(ref[0], out[b, :, :320 * n]) >= 45.0, (b, n)
+        assert float(out[b, :, 320 * n:].abs().max()) == 0.0 if n < 37 else True
 
 
 def test_config_and_checkpoint_drop_in(tmp_path, built):
