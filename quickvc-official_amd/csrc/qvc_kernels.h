@@ -33,13 +33,15 @@ struct Ragged {
 //  copy the whole argument struct to scratch memory -- measured: 296 B of scratch and half the occupancy)
 QVC_HD int ragged_len(const Ragged r, int b, int T) {          // hi
   if (!r.lens) return T;
-  const int n = (r.lens[b] - (r.pos ? r.pos[b] - r.off : 0)) * r.mul + r.add;
+  int d = r.lens[b] - (r.pos ? r.pos[b] - r.off : 0);          // unit frames of the sequence left from buffer row 0
+  d = d < 0 ? 0 : (d < T ? d : T);                             // clamped BEFORE scaling: "unknown length" is 2^30
+  const int n = d * r.mul + r.add;
   return n < 0 ? 0 : (n < T ? n : T);
 }
 QVC_HD int ragged_lo(const Ragged r, int b) {                  // lo
   if (!r.pos) return 0;
-  const int n = (r.off - r.pos[b]) * r.mul;
-  return n < 0 ? 0 : n;
+  const int d = r.off - r.pos[b];
+  return d <= 0 ? 0 : d * r.mul;
 }
 
 // Arguments of one implicit-GEMM conv launch.  All strides in elements.
