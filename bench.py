@@ -101,19 +101,20 @@ def main() -> None:
     # ---- one step, optionally as a hipGraph (the library call is capturable: no sync/alloc inside)
     stream = torch.cuda.Stream(device)
     graph = None
+    ws = engine.alloc_workspace(B, FRAMES)                   # the graph bakes its pointer in: owned here, not shared
     with torch.cuda.stream(stream):
-        engine.infer_batch(unit, g, noise, out)              # allocates workspace, loads code objects
+        engine.infer_batch(unit, g, noise, out, ws=ws)       # loads code objects
         stream.synchronize()
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                engine.infer_batch(unit, g, noise, out)
+                engine.infer_batch(unit, g, noise, out, ws=ws)
 
     def step():
         if graph is not None:
             graph.replay()
         else:
-            engine.infer_batch(unit, g, noise, out)
+            engine.infer_batch(unit, g, noise, out, ws=ws)
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):

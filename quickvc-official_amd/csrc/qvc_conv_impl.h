@@ -114,6 +114,10 @@ __device__ __forceinline__ f16x8 lrelu8<_Float16>(f16x8 v, float slope) {
 #ifndef QVC_PF_WN
 #define QVC_PF_WN 3
 #endif
+// prefetch depth of the whole-stack WaveNet kernel (weight-stream bound: see DESIGN.md)
+#ifndef QVC_PF_STACK
+#define QVC_PF_STACK 3
+#endif
 
 // gemm_prime issues the first kPF k-steps of a stream into the ring; gemm_loop_primed runs the K loop on a ring
 // primed that way.  (Priming the NEXT GEMM's ring before the epilogue and barrier of the current one was tried
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
       for (int n = 0; n < NF; ++n) pacc[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* app = static_cast<const frag*>(a.w_pre) + ((size_t)wm * a.pre_KS * FW) * 64 + lane;
-    gemm_loop<T, FW, NF, QVC_PF_CONV>(pacc, app, a.pre_KS, a.pre_KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+    gemm_loop<T, FW, NF, QVC_PF_STACK>(pacc, app, a.pre_KS, a.pre_KS, 1, acts, rowbytes, sm, lrow, lq, 0);
 #pragma unroll
     for (int f = 0; f < FW; ++f) {
       const int ch0 = (wm * FW + f) * 16 + lq * 4;
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
         for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       const frag* ap = static_cast<const frag*>(a.w_in[l]) + ((size_t)wm * a.nIt1 * MF) * 64 + lane;
-      if (!QVC_ABL(1)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, 0);
+      if (!QVC_ABL(1)) gemm_loop<T, MF, NF, QVC_PF_STACK>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, 0);
       const float* bb = a.bbias + (size_t)b * a.bbias_bs + (size_t)l * 2 * a.H;
 #pragma unroll
       for (int f = 0; f < FW; ++f) {
@@ -1269,7 +1273,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       const float* brs = a.b_rs[l];
       if (!last) {
         const frag* ap = static_cast<const frag*>(a.w_rs[l]) + ((size_t)wm * a.KS * MF) * 64 + lane;
-        if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+        if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_STACK>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
 #pragma unroll
         for (int f = 0; f < FW; ++f) {
           const int ch0 = (wm * FW + f) * 16 + lq * 4;
@@ -1294,7 +1298,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       } else {
         f32x4 (&acl)[FW][NF] = reinterpret_cast<f32x4 (&)[FW][NF]>(acc);
         const frag* ap = static_cast<const frag*>(a.w_rs[l]) + ((size_t)wm * a.KS * FW) * 64 + lane;
-        gemm_loop<T, FW, NF, QVC_PF_CONV>(acl, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+        gemm_loop<T, FW, NF, QVC_PF_STACK>(acl, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
 #pragma unroll
         for (int f = 0; f < FW; ++f) {
           const int ch0 = (wm * FW + f) * 16 + lq * 4;
@@ -1341,7 +1345,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
         for (int n = 0; n < ON; ++n) qacc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       const frag* apq = static_cast<const frag*>(a.w_post) + ((size_t)wm * a.KS * PM) * 64 + lane;
-      gemm_loop<T, PM, ON, QVC_PF_CONV>(qacc, apq, a.KS, a.KS, 1, acts, rowbytes, sm, OLO * 16 + lrow, lq, 0);
+      gemm_loop<T, PM, ON, QVC_PF_STACK>(qacc, apq, a.KS, a.KS, 1, acts, rowbytes, sm, OLO * 16 + lrow, lq, 0);
 #pragma unroll
       for (int m = 0; m < PM; ++m) {
         const int v = (wm * PM + m) * 16 + lq * 4;

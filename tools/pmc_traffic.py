@@ -29,9 +29,10 @@ def pretty(name):
     m = re.search(r"rbpair_persist_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)E", name)
     if m:
         return f"rbpair_persist<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)}>"
-    m = re.search(r"rbpair_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi\d+E", name)
-    if m:
-        return f"rbpair<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)}>"
+    m = re.search(r"rbpair_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi\d+E(DF16_)?", name)
+    if m:   # 6th template argument = stream type: spelled out (DF16_) only when it differs from the operand type
+        t = "f16" if m.group(1) == "DF16_" else ("bf16x" if m.group(5) else "bf16")
+        return f"rbpair<{t},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)}>"
     m = re.search(r"conv_mfma_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"conv<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)},{'gau' if m.group(5) == '1' else 'std'}>"
