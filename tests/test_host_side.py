@@ -107,6 +107,14 @@ def test_pack_weights_error_codes(built):
     assert built.qvc_workspace_bytes(ctypes.byref(cfg4), 2, 50) == -2 and built.qvc_blob_bytes(ctypes.byref(cfg4)) == -2
     mc5 = dict(model.model_config); mc5["upsample_rates"] = [4, 4]; mc5["upsample_kernel_sizes"] = [15, 16]   # 15-4+1 even, 16-4+1-1 even
     assert built.qvc_workspace_bytes(ctypes.byref(L.make_config(mc5)), 2, 50) > 0
+    # streaming queries: sizes grow with the hop, the lag is the sum of the segments' reaches, bad arguments are codes
+    assert built.qvc_stream_lag_frames(ctypes.byref(cfg)) == 32 + 4 * 8 + 20 + 6 and built.qvc_stream_noise_lag_frames(ctypes.byref(cfg)) == 32
+    s16, s320 = built.qvc_stream_state_bytes(ctypes.byref(cfg), 4, 16), built.qvc_stream_state_bytes(ctypes.byref(cfg), 4, 320)
+    assert 0 < s16 < s320 and built.qvc_stream_workspace_bytes(ctypes.byref(cfg), 4, 16) > 0
+    assert built.qvc_stream_state_bytes(ctypes.byref(cfg), 4, 0) == -1 and built.qvc_stream_state_bytes(ctypes.byref(cfg), 0, 16) == -1
+    mc6 = dict(model.model_config); mc6["upsample_rates"] = [20]; mc6["upsample_kernel_sizes"] = [41]; mc6["upsample_initial_channel"] = 16
+    assert built.qvc_stream_state_bytes(ctypes.byref(L.make_config(mc6)), 4, 16) == -2            # streaming needs two up-samplers
+    assert built.qvc_stream_step(ctypes.byref(cfg), None, None, 0, None, None, None, None, 1, 16, None, None, None, 0, None) == -1
 
 
 def test_speaker_encoder_pack_and_host_emulation(built):
