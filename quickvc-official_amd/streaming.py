@@ -167,9 +167,11 @@ class StreamConverter:
         return out
 
     @torch.no_grad()
-    def convert(self, unit: torch.Tensor, g: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def convert(self, unit: torch.Tensor, g: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Convenience: stream whole utterances through the step interface.  unit (S, 256, T), g (S, gin),
-        noise (S, inter, T) -> (S, 1, T * samples_per_frame); equals infer_batch on the whole thing."""
+        noise (S, inter, T) -> (S, 1, T * samples_per_frame); equals infer_batch on the whole thing.  ``lengths`` (S,):
+        streams that end before T (their rows are zero after the end, as with infer_batch_ragged)."""
         S, UC, T = unit.shape
         if S != self.streams:
             raise ValueError(f"built for {self.streams} streams, got {S}")
@@ -179,7 +181,7 @@ class StreamConverter:
             noise = torch.randn(S, inter, T, device=dev)
         unit, noise = unit.to(dev, torch.float32), noise.to(dev, torch.float32)
         h, lag, nl, spf = self.hop, self.lag, self.noise_lag, self.spf
-        self.reset(g.to(dev, torch.float32), torch.full((S,), T, dtype=torch.int32))
+        self.reset(g.to(dev, torch.float32), torch.full((S,), T, dtype=torch.int32) if lengths is None else lengths)
         out = torch.zeros(S, 1, T * spf, device=dev)
         pad_u = torch.nn.functional.pad(unit, (0, h + lag))                      # frames past the end: ignored by the kernels
         pad_n = torch.nn.functional.pad(noise, (nl, h + lag))                    # frame f of the noise sits at column f + nl

@@ -486,6 +486,57 @@ def test_incremental_streaming_at_stated_size(lib, dev, hop, T):
     assert snr_db(whole.cpu(), streamed.cpu()) >= 90.0
 
 
+def test_streams_of_different_lengths_in_the_mixed_operand_mode(lib, dev):
+    """Streams that end at different frames, `bf16x` operands, hop 40: every stream's concatenated step outputs
+    equal that stream converted alone through the offline path in the same operand mode (the stream ends inside a
+    window, later steps see only padding), zeros after its end."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd.streaming import StreamConverter
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    model = q.SynthesizerTrn(641, 32, **dict(entry["config"], operand_dtype="bf16x"))
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    lens = [200, 143, 57]
+    unit, g, noise = make_synthetic_inputs(3, 200, 256, 192, 256, seed0=7100)
+    conv = StreamConverter(model, streams=3, hop_frames=40, use_graph=True)
+    streamed = conv.convert(unit.cuda(), g.cuda(), noise.cuda(), lengths=torch.tensor(lens, dtype=torch.int32))
+    torch.cuda.synchronize()
+    for b, n in enumerate(lens):
+        alone = model.infer_batch(unit[b:b + 1, :, :n].cuda(), g[b:b + 1].cuda(), noise[b:b + 1, :, :n].cuda())
+        assert snr_db(alone[0].cpu(), streamed[b, :, :320 * n].cpu()) >= 90.0, (b, n)
+        if n < 200:
+            assert float(streamed[b, :, 320 * n:].abs().max()) == 0.0
+
+
+def test_ragged_batch_at_benchmark_size(lib, dev):
+    """B = 32 utterances of random lengths in [100, 250] (the corpus case, BASELINE configs[3]) in ONE ragged
+    call, `bf16x` operands: finite, zeros after every end, and three members spot-checked against the same
+    utterance converted alone (>= 100 dB) and against the fp32 oracle (>= 40 dB, the mode's bar)."""
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "bf16x")
+    rs = np.random.RandomState(11)
+    lens = [int(x) for x in rs.randint(100, 251, size=32)]
+    lens[5] = 250
+    unit, g, noise = make_synthetic_inputs(32, 250, 256, 192, 256, seed0=8000)
+    out = eng.infer_batch_ragged(unit.to(dev), g.to(dev), noise.to(dev), torch.tensor(lens, dtype=torch.int32))
+    torch.cuda.synchronize()
+    assert out.shape == (32, 1, 80000) and bool(torch.isfinite(out).all())
+    for b, n in enumerate(lens):
+        if n < 250:
+            assert float(out[b, :, 320 * n:].abs().max()) == 0.0, b
+    for b in (0, 5, 31):
+        n = lens[b]
+        alone = eng.infer_batch(unit[b:b + 1, :, :n].to(dev), g[b:b + 1].to(dev), noise[b:b + 1, :, :n].to(dev))
+        torch.cuda.synchronize()
+        assert snr_db(alone[0].cpu(), out[b, :, :320 * n].cpu()) >= 100.0, (b, n)
+        ref = oracle.infer_from_g(sd, entry["config"], unit[b:b + 1, :, :n], g[b:b + 1].unsqueeze(-1), noise[b:b + 1, :, :n])
+        assert snr_db(ref[0], out[b, :, :320 * n].cpu()) >= 40.0, (b, n)
+
+
 def test_wide_config_takes_the_fallback_paths(lib, dev):
     """A config the fused pair kernel does not cover: stage-1 ResBlocks 416 channels wide (two M chunks -> the
     conv1 / conv2 launches with an operand-type residual instead of the fused pair); WaveNet width 256 = the
