@@ -726,38 +726,42 @@ def test_convert_cli_end_to_end(lib, dev, tmp_path):
         assert snr_db(ref[0, 0].cpu().numpy(), got) >= 100.0, name
 
 
-def test_convert_cli_on_the_reference_demo_pair(lib, dev, tmp_path):
-    """BASELINE configs[0] with the pair the reference names in convert.txt: source p225_001.wav (26 007 samples ->
-    81 unit frames; units are synthetic because HuBERT-soft cannot be fetched), target p226_005.wav (real speech:
-    load -> energy trim -> HIP mel -> HIP speaker encoder).  The written file follows the reference's output
+def test_convert_cli_on_the_shape_of_the_reference_demo_pair(lib, dev, tmp_path):
+    """BASELINE configs[0] (`p225_001.wav -> p226_005.wav`) with stand-ins of the same shape: the reference's demo
+    recordings cannot travel to the GPU box, so a 26 007-sample 16-bit source (-> 81 unit frames; units are synthetic
+    anyway because HuBERT-soft cannot be fetched) and a 120 744-sample speech-like target (load -> energy trim ->
+    HIP mel -> HIP speaker encoder) are synthesised here.  The written file follows the reference's output
     convention (output/quickvc/*.wav): float32, 16 kHz, 320 samples per unit frame = 25 920 samples."""
     import json
-    import os
     from scipy.io import wavfile
-    import helpers
     import quickvc_official_amd as q
     from quickvc_official_amd import convert as cli
     from quickvc_official_amd.checkpoint import save_checkpoint
     from quickvc_official_amd.frontend import load_wav, trim
     from quickvc_official_amd.synth import make_synthetic_state_dict
-    wavs = os.path.join(helpers.GOLDEN, "wav")
     cfg = {"train": {"segment_size": 10240}, "data": dict(q.DEFAULT_DATA_CONFIG), "model": dict(q.DEFAULT_MODEL_CONFIG)}
     (tmp_path / "config.json").write_text(json.dumps(cfg))
     model = q.SynthesizerTrn(641, 32, **q.DEFAULT_MODEL_CONFIG)
     model.load_state_dict(make_synthetic_state_dict(model, 1234))
     save_checkpoint(model, None, 2e-4, 1, str(tmp_path / "G_1.pth"))
-    src = load_wav(os.path.join(wavs, "p225_001.wav"), 16000)
-    assert len(src) == 26007
-    frames = len(src) // 320                                        # HuBERT-soft's 20 ms hop: 81 frames
+
+    def speechlike(n, seed):                                        # voiced bursts between silences, int16
+        rs = np.random.RandomState(seed)
+        t = np.arange(n) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * (140.0 + 30.0 * np.sin(2 * np.pi * 0.7 * t)) * t) + 0.02 * rs.randn(n)
+        x *= (np.sin(2 * np.pi * 0.9 * t) > -0.2) * (t > 0.15) * (t < t[-1] - 0.2)
+        return (np.clip(x, -1, 1) * 32767).astype(np.int16)
+    wavfile.write(str(tmp_path / "p225_001.wav"), 16000, speechlike(26007, 1))
+    wavfile.write(str(tmp_path / "p226_005.wav"), 16000, speechlike(120744, 2))
+    frames = 26007 // 320                                           # HuBERT-soft's 20 ms hop: 81 frames
     np.save(str(tmp_path / "p225_001.npy"), np.random.RandomState(1).randn(frames, 256).astype(np.float32))
-    os.symlink(os.path.join(wavs, "p225_001.wav"), str(tmp_path / "p225_001.wav"))
-    (tmp_path / "convert.txt").write_text(f"title1|{tmp_path}/p225_001.wav|{wavs}/p226_005.wav\n")
+    (tmp_path / "convert.txt").write_text(f"title1|{tmp_path}/p225_001.wav|{tmp_path}/p226_005.wav\n")
     cli.main(["--hpfile", str(tmp_path / "config.json"), "--ptfile", str(tmp_path / "G_1.pth"), "--txtpath", str(tmp_path / "convert.txt"),
               "--outdir", str(tmp_path / "out"), "--seed", "1"])
     rate, got = wavfile.read(str(tmp_path / "out" / "title1.wav"))
     assert rate == 16000 and got.dtype == np.float32 and got.shape == (320 * 81,) and np.isfinite(got).all()
-    tgt = load_wav(os.path.join(wavs, "p226_005.wav"), 16000)
-    assert len(tgt) == 120744 and 0 < len(trim(tgt, top_db=20)) <= len(tgt)
+    tgt = load_wav(str(tmp_path / "p226_005.wav"), 16000)
+    assert len(tgt) == 120744 and 0 < len(trim(tgt, top_db=20)) < len(tgt)
 
 
 def test_convert_cli_two_ranks_rehearsal(lib, dev, tmp_path):

@@ -435,7 +435,7 @@ def test_frontend_and_cli_planning():
     assert sorted(i for b in plan for i in b) == list(range(1000)) and max(len(b) for b in plan) <= 32
     assert all(min(lens[i] for i in b) >= 0.75 * max(lens[i] for i in b) for b in plan)
     assert len(plan) <= 60                                          # a corpus does not degenerate to batch-1 launches
-    ref = os.path.join(ROOT, "tests", "golden", "wav", "p225_001.wav")
-    if os.path.exists(ref):                                         # the reference's own demo input (fixture copy)
+    ref = os.path.join(ROOT, "..", "reference", "test_data", "p225_001.wav")
+    if os.path.exists(ref):                                         # container only: the reference's own demo input
         w = F.load_wav(ref, 16000)
         assert w.dtype == np.float32 and abs(len(w) - 26007) <= 1 and np.abs(w).max() <= 1.0
