@@ -346,6 +346,18 @@ struct EmuBackend {
         }
     return QVC_OK;
   }
+  // conv_post + tail as one backend op (qvc_post_tail_impl.h): the same two steps through a host buffer
+  bool post_tail_ok(const ConvDesc&) const { return true; }
+  int post_tail(const ConvDesc& d, const PostTailArgs& a, int batch, int dtype) {
+    std::vector<float> post((size_t)batch * a.F * 72, 0.f);
+    ConvArgs c = a.c;
+    c.y32 = post.data(); c.y32_bs = (int64_t)a.F * 72; c.y32_ts = 72;
+    const int st = conv(d, c, batch, EPI_STD, dtype);
+    if (st != QVC_OK) return st;
+    TailArgs ta{post.data(), a.fir, a.out, nullptr, batch, a.F};
+    ta.rg = a.rg;
+    return tail(ta);
+  }
   // Tail: same formulas as istft_synth_kernel, evaluated sample by sample.
   int tail(const TailArgs& a) {
     const int Fpad = a.F, Lpad = 4 * (Fpad - 1), NOpad = 4 * Lpad;
@@ -494,8 +506,7 @@ int qvc_emu_infer_batch(const qvc_config* cfg, const void* blob, const float* un
   c.cond_table(g);
   c.enc_p(unit, noise, c.wsp<float>(r.W.z));
   c.flow(c.wsp<float>(r.W.z));
-  c.dec_trunk(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post));
-  c.tail(c.wsp<float>(r.W.post), out, nullptr, frames * r.P.total_up + 1);
+  c.dec_trunk_wave(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post), out);
   return c.status;
 }
 
@@ -511,8 +522,7 @@ int qvc_emu_infer_batch_ragged(const qvc_config* cfg, const void* blob, const fl
   c.cond_table(g);
   c.enc_p(unit, noise, c.wsp<float>(r.W.z));
   c.flow(c.wsp<float>(r.W.z));
-  c.dec_trunk(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post));
-  c.tail(c.wsp<float>(r.W.post), out, nullptr, max_frames * r.P.total_up + 1);
+  c.dec_trunk_wave(c.wsp<float>(r.W.z), c.wsp<float>(r.W.post), out);
   return c.status;
 }
 

@@ -81,6 +81,8 @@ struct HipBackend {
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
+  bool post_tail_ok(const ConvDesc& d) const { return post_tail_mode() != 0 && post_tail_supported(d); }
+  int post_tail(const ConvDesc& d, const PostTailArgs& a, int batch, int dtype) { return launch_post_tail(d, a, batch, dtype, stream); }
   int zero(void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; }
   int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
@@ -180,6 +182,17 @@ struct TimedBackend {
     note("sample", 0, (double)a.batch * a.frames * a.C * 16); return st; }
   int tail(const TailArgs& a) { if (ev.empty()) mark(); int st = launch_tail(a, stream); mark();
     note("istft_synth", 0, (double)a.batch * ((double)a.F * 72 * 4 + 16.0 * (a.F - 1) * 4)); return st; }
+  bool post_tail_ok(const ConvDesc& d) const { return post_tail_mode() != 0 && post_tail_supported(d); }
+  int post_tail(const ConvDesc& d, const PostTailArgs& a, int batch, int dtype) {
+    if (ev.empty()) mark();
+    int st = launch_post_tail(d, a, batch, dtype, stream);
+    mark();
+    char name[48];
+    std::snprintf(name, sizeof(name), "post_tail<%s>", dtype == QVC_F16 ? "f16" : "bf16");
+    note(name, 2.0 * batch * (double)a.F * d.M * d.taps * d.Cin,
+         (double)batch * ((double)a.c.T_in * d.Cin * 2 * 3 + 16.0 * (a.F - 1) * 4) + (double)d.w_bytes());
+    return st;
+  }
   int zero(void* p, size_t bytes) { if (ev.empty()) mark(); int st = hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; mark();
     note("memset", 0, (double)bytes); return st; }
   int finish() {
@@ -282,8 +295,7 @@ int qvc_infer_batch_ex(const qvc_config* cfg, const void* blob_dev, const float*
   c.cond_table(g);
   c.enc_p(unit, noise, c.wsp<float>(W.z));
   c.flow(c.wsp<float>(W.z));
-  c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
-  c.tail(c.wsp<float>(W.post), out, nullptr, frames * P.total_up + 1);
+  c.dec_trunk_wave(c.wsp<float>(W.z), c.wsp<float>(W.post), out);
   return c.status != QVC_OK ? c.status : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
 }
 
@@ -300,8 +312,7 @@ int qvc_infer_batch_ragged(const qvc_config* cfg, const void* blob_dev, const fl
   c.cond_table(g);
   c.enc_p(unit, noise, c.wsp<float>(W.z));
   c.flow(c.wsp<float>(W.z));
-  c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
-  c.tail(c.wsp<float>(W.post), out, nullptr, max_frames * P.total_up + 1);
+  c.dec_trunk_wave(c.wsp<float>(W.z), c.wsp<float>(W.post), out);
   return c.status != QVC_OK ? c.status : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
 }
 
@@ -365,8 +376,7 @@ int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev, const flo
   c.cond_table(g);
   c.enc_p(unit, noise, c.wsp<float>(W.z));
   c.flow(c.wsp<float>(W.z));
-  c.dec_trunk(c.wsp<float>(W.z), c.wsp<float>(W.post));
-  c.tail(c.wsp<float>(W.post), out, nullptr, frames * P.total_up + 1);
+  c.dec_trunk_wave(c.wsp<float>(W.z), c.wsp<float>(W.post), out);
   const int fin = be.finish();
   *n_records = be.n;
   return c.status != QVC_OK ? c.status : fin;

@@ -122,17 +122,19 @@ __device__ __forceinline__ f16x8 lrelu8<_Float16>(f16x8 v, float slope) {
 // gemm_prime issues the first kPF k-steps of a stream into the ring; gemm_loop_primed runs the K loop on a ring
 // primed that way.  (Priming the NEXT GEMM's ring before the epilogue and barrier of the current one was tried
 // in the WaveNet stack kernel -- 8 short GEMMs per launch -- and bought nothing: 14.3 vs 14.1 us per layer.)
-template <typename T, int MF, int kPF>
+// AS = fragments per k-step in the stream (default MF: the wave walks all of its packed fragments; a wave that
+// skips all-padding fragments of its rows walks the first MF of AS)
+template <typename T, int MF, int kPF, int AS = MF>
 __device__ __forceinline__ void gemm_prime(typename Op<T>::frag (&ar)[kPF + 1][MF], const typename Op<T>::frag* ap, int nIt) {
 #pragma unroll
   for (int u = 0; u < kPF; ++u)
     if (u < nIt) {
 #pragma unroll
-      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)u * MF + m) * 64];
+      for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)u * AS + m) * 64];
     }
 }
 
-template <typename T, int MF, int NF, int kPF>
+template <typename T, int MF, int NF, int kPF, int AS = MF>
 __device__ __forceinline__ void gemm_loop_primed(f32x4 (&acc)[MF][NF], typename Op<T>::frag (&ar)[kPF + 1][MF],
                                                  const typename Op<T>::frag* ap, int nIt, int KS, int dil,
                                                  const char* tile, int rowbytes, Swz sm, int colrow, int lq) {
@@ -165,7 +167,7 @@ __device__ __forceinline__ void gemm_loop_primed(f32x4 (&acc)[MF][NF], typename 
       if (it < nIt) {                                           // wave-uniform
         if (it + kPF < nIt && !QVC_ABL(5)) {
 #pragma unroll
-          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pf * MF + m) * 64];
+          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pf * AS + m) * 64];
           ++pf;
         }
         if (it + 1 < nIt && !QVC_ABL(6)) read_b(bf[(u + 1) & 1]);
@@ -185,12 +187,12 @@ __device__ __forceinline__ void gemm_loop_primed(f32x4 (&acc)[MF][NF], typename 
 // A fragments go through a register ring, prefetched kPF k-steps ahead with plain loads (hipcc tracks
 // them).  An inline-asm variant with hand-counted vmcnt waits was tried and rejected: no faster, and
 // the compiler copied not-yet-landed asm outputs in one instantiation (wrong results).
-template <typename T, int MF, int NF, int kPF>
+template <typename T, int MF, int NF, int kPF, int AS = MF>
 __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int dil,
                                           const char* tile, int rowbytes, Swz sm, int colrow, int lq, int /*rot*/) {
   typename Op<T>::frag ar[kPF + 1][MF];
-  gemm_prime<T, MF, kPF>(ar, ap, nIt);
-  gemm_loop_primed<T, MF, NF, kPF>(acc, ar, ap, nIt, KS, dil, tile, rowbytes, sm, colrow, lq);
+  gemm_prime<T, MF, kPF, AS>(ar, ap, nIt);
+  gemm_loop_primed<T, MF, NF, kPF, AS>(acc, ar, ap, nIt, KS, dil, tile, rowbytes, sm, colrow, lq);
 }
 
 // The K loop for ONE WAVE PER SIMD (persistent pair kernel).  With a partner wave on the SIMD the loop above is

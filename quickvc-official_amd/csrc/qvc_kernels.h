@@ -156,6 +156,21 @@ struct TailArgs {     // models.py:394-406 / pqmf.py:106-117
   Ragged rg;          // per-utterance frame count min(F, lens*mul + add); samples past it are written as zeros
 };
 
+// subband_conv_post + tail in one launch (qvc_post_tail_impl.h): `c` = the conv_post launch without an output
+// pointer, the rest = TailArgs.  The post-conv frames stay in the CU.
+struct PostTailArgs {
+  ConvArgs c;
+  const float* fir = nullptr;   // [subbands][63], gain folded
+  float* out = nullptr;         // [B][16*(F-1)]
+  int32_t F = 0;                // post-conv frames (= c.T_in + 1)
+  Ragged rg;                    // as TailArgs::rg
+};
+// the fused kernel walks conv_post's packed weights as 2 waves x 3 row fragments and a 128-frame tile
+inline bool post_tail_supported(const ConvDesc& d) {
+  return d.M == 72 && d.MF == 3 && d.WM == 2 && d.nchunk == 1 && d.up_s == 1 && d.dil == 1 && !d.gau && !d.lp &&
+         (int64_t)(128 + d.taps - 1) * d.CinP * 2 <= 96 * 1024;
+}
+
 // One LSTM layer's recurrence over all partials (models.py:510,516): gates = xp[t] + W_hh h[t-1], PyTorch gate
 // order i,f,g,o.  The input projection xp (with b_ih + b_hh) comes from a conv launch.
 struct LstmArgs {
@@ -190,11 +205,16 @@ int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream,
 int launch_gemv(const GemvArgs& a, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
 int launch_tail(const TailArgs& a, void* stream);
+int launch_post_tail(const ConvDesc& d, PostTailArgs a, int batch, int dtype, void* stream);
+// Developer / test switch (environment QVC_POST_TAIL, read on first use): 1 (default) fuse conv_post + tail where
+// post_tail_supported(); 0: always two launches
+int& post_tail_mode();
 
 // Instantiation entry (one translation unit per operand dtype).
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);
 template <typename T> int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream);
 template <typename T> int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream, int* nf_out);
+template <typename T> int launch_post_tail_typed(const ConvDesc& d, const PostTailArgs& a, int batch, void* stream);
 template <typename T, typename TS> int launch_pair_typed(const ConvDesc* d1, const PairArgs3& a, int batch, void* stream, int* nf_out);   // TS: stream type
 
 }  // namespace qvc

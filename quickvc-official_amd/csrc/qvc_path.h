@@ -242,7 +242,11 @@ struct Path {
   }
   void dec_front(const float* z) { dec_part(z, nullptr, 0, 1, true, false); }
   void dec_back(float* post_out) { dec_part(nullptr, post_out, 1, (int)P.stages.size(), false, true); }
-  void dec_part(const float* z, float* post_out, int stage_lo, int stage_hi, bool with_pre, bool with_post) {
+  // ... all the way to the waveform: conv_post and the tail as ONE launch where the backend has it (the post-conv
+  // frames then never reach `post_buf`), else conv_post -> post_buf -> tail
+  void dec_trunk_wave(const float* z, float* post_buf, float* wave) { dec_part(z, post_buf, 0, (int)P.stages.size(), true, true, wave); }
+  void dec_back_wave(float* post_buf, float* wave) { dec_part(nullptr, post_buf, 1, (int)P.stages.size(), false, true, wave); }
+  void dec_part(const float* z, float* post_out, int stage_lo, int stage_hi, bool with_pre, bool with_post, float* wave = nullptr) {
     const qvc_config& c = P.cfg;
     const int C = c.inter_channels, C0 = c.upsample_initial_channel;
     if (with_pre) {   // conv_pre(k7) + cond(g), then the first stage's leaky ReLU fused into the store
@@ -365,8 +369,17 @@ struct Path {
       a.x_bs = (int64_t)t_in * ch_in; a.x_ts = ch_in;
       a.T_in = t_in; a.slope_in = 0.01f; a.reflect = 1;
       a.Nq = t_in + 1; a.T_out = t_in + 1; a.rg = rg(rate);
+      if (wave && be.post_tail_ok(P.conv_post)) {
+        if (status != QVC_OK) return;
+        PostTailArgs pt;
+        pt.c = a; pt.fir = reinterpret_cast<const float*>(blob + P.fir_off); pt.out = wave; pt.F = t_in + 1;
+        pt.rg = rg(P.total_up, 1);
+        status = be.post_tail(P.conv_post, pt, B, dtype_dec());
+        return;
+      }
       a.y32 = post_out; a.y32_bs = (int64_t)(t_in + 1) * P.post_channels; a.y32_ts = P.post_channels;
       conv(P.conv_post, a, dtype_dec());
+      if (wave) tail(post_out, wave, nullptr, t_in + 1);
     }
   }
 

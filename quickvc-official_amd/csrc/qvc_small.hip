@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include "qvc_launch_util.h"
 #include "qvc_kernels.h"
+#include "qvc_tail_impl.h"
 
 namespace qvc {
 
@@ -96,21 +97,17 @@ int launch_sample(const SampleArgs& a, void* stream) {
 }
 
 // ------------------------------------------------------------------ iSTFT + band synthesis tail
-// Geometry (n_fft 16, hop 4, 4 sub-bands, 63 taps):
-//   band signal   y_k[n], n in [0, 4(F-1)):  y = (sum_t w[m] x_t[m]) / (sum_t w[m]^2), m = n + 8 - 4t
-//   output        out[o], o in [0, 16(F-1)): out[o] = sum_k sum_n fir[k][4n - o + 31] * y_k[n]
+// (formulas and the per-item math: qvc_tail_impl.h)
 // One block = kOT consecutive output samples = kOT/4 band samples (+-7/8 halo) = kOT/16 frames (+-3/4).
 constexpr int kOT = 912;                   // output samples per block: 57 + 7 = 64 frames x 4 bands = exactly one
                                            // (frame, band) item per thread in the DFT phase (1024 needed two rounds)
 constexpr int kNY = kOT / 4 + 15;          // band samples needed: [a0-7, a0+kOT/4+7]
 constexpr int kNFR = kOT / 16 + 7;         // frames needed: [f0-3, f0+kOT/16+3]
-constexpr int kBands = 4, kBins = 9, kPostC = kBands * 2 * kBins, kTaps = 63;
 
 __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   __shared__ __attribute__((aligned(16))) float s_post[kNFR * kPostC];    // 20.4 KB
   __shared__ float s_xw[kBands][kNFR][17];                                // windowed frames (padded)
   __shared__ float s_y[kBands][kNY + 1];
-  __shared__ float s_fir[kBands * 64];
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -141,49 +138,15 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
       if (i < kChunks) *reinterpret_cast<float4*>(&s_post[i * 4]) = v[u];
     }
   }
-  if (tid < kBands * 64) {
-    const int k = tid >> 6, j = tid & 63;
-    s_fir[tid] = j < kTaps ? a.fir[k * kTaps + j] : 0.f;
-  }
   __syncthreads();
 
   // ---- per (frame, band): polar -> 16-point inverse real DFT -> Hann window
-  constexpr float kPi = 3.14159265358979323846f;
   for (int item = tid; item < kNFR * kBands; item += 256) {
     const int fr = item >> 2, k = item & 3;
-    const float* sp = &s_post[fr * kPostC + k * 2 * kBins];
-    float re[kBins], im[kBins];
+    float xw[16];
+    tail_dft(&s_post[fr * kPostC + k * 2 * kBins], xw);
 #pragma unroll
-    for (int q = 0; q < kBins; ++q) {
-      // hardware transcendentals: v_exp_f32 (1 ulp), v_sin/v_cos_f32 take revolutions.  The phase
-      // pi*sin(p) lies in [-pi, pi] = [-0.5, 0.5] revolutions, the sweet spot of v_sin/v_cos (abs err
-      // ~1e-6); p itself is reduced with an exact fract() first.
-      const float mag = __builtin_amdgcn_exp2f(1.4426950408889634f * sp[q]);
-      const float pr = sp[kBins + q] * 0.15915494309189535f;              // p / 2pi
-      const float sp_ = __builtin_amdgcn_sinf(pr - floorf(pr));            // sin(p)
-      const float rev = 0.5f * sp_;                                        // pi*sin(p) / 2pi
-      re[q] = mag * __builtin_amdgcn_cosf(rev); im[q] = mag * __builtin_amdgcn_sinf(rev);
-    }
-    // twiddles cos/sin(2*pi*j/16), j = 0..15, as compile-time constants after unrolling
-    constexpr float C16[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
-                               -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
-                               -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.f,
-                               0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
-    constexpr float S16[16] = {0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.f,
-                               0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
-                               -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
-                               -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      float acc = re[0] + ((m & 1) ? -re[8] : re[8]);      // imaginary parts of bins 0 and 8 are ignored
-#pragma unroll
-      for (int q = 1; q < 8; ++q) {
-        const int j = (q * m) & 15;
-        acc += 2.f * (re[q] * C16[j] - im[q] * S16[j]);
-      }
-      const float win = 0.5f - 0.5f * C16[m];               // periodic Hann(16)
-      s_xw[k][fr][m] = acc * (1.f / 16.f) * win;
-    }
+    for (int m = 0; m < 16; ++m) s_xw[k][fr][m] = xw[m];
   }
   __syncthreads();
 
@@ -191,25 +154,7 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   for (int item = tid; item < kNY * kBands; item += 256) {
     const int k = item / kNY, i = item - k * kNY;
     const int n = a0 - 7 + i;
-    float y = 0.f;
-    if (n >= 4 * Flo && n < L) {
-      constexpr float C16b[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
-                                  -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
-                                  -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.f,
-                                  0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
-      float num = 0.f, env = 0.f;
-      const int t_hi = (n + 8) >> 2;                         // frames with m = n + 8 - 4t in [0, 16)
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int t = t_hi - d, m = n + 8 - 4 * t;
-        if (t >= Flo && t < Fb && m < 16) {
-          const float w = 0.5f - 0.5f * C16b[m];
-          num += s_xw[k][t - f_lo][m];
-          env += w * w;
-        }
-      }
-      y = num / env;
-    }
+    const float y = tail_ola(n, Flo, Fb, L, [&](int t, int m) { return s_xw[k][t - f_lo][m]; });
     s_y[k][i] = y;
     if (a.y_mb && i >= 7 && i < 7 + kOT / 4 && n < Lpad)
       a.y_mb[((size_t)b * kBands + k) * Lpad + n] = y;
@@ -219,19 +164,8 @@ __global__ __launch_bounds__(256) void istft_synth_kernel(const TailArgs a) {
   // ---- polyphase synthesis FIR: thread -> 4 consecutive outputs o = o0 + 4*tid + r
   if (tid < kOT / 4) {
     const int ia = tid + 7;                                  // s_y index of band sample a = a0 + tid
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < kBands; ++k) {
-#pragma unroll
-      for (int d = -7; d <= 8; ++d) {
-        const float yv = s_y[k][ia + d];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 4 * d - r + 31;                      // tap index, compile-time after unrolling
-          if (j >= 0 && j < kTaps) out[r] = fmaf(s_fir[k * 64 + j], yv, out[r]);
-        }
-      }
-    }
+    float out[4];
+    tail_fir<kTaps>([&](int k, int d) { return s_y[k][ia + d]; }, a.fir, out);
     const int o = o0 + 4 * tid;
     const int n_out = 4 * Lpad;
     if (o >= 4 * L || o < 16 * Flo) out[0] = out[1] = out[2] = out[3] = 0.f;   // outside this utterance (both bounds are multiples of 4)
@@ -279,6 +213,20 @@ int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, vo
   a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout;
   if (dtype == QVC_F16) return launch_conv_typed<_Float16>(d, a, batch, epi, stream, nf_out);
   if (dtype == QVC_BF16) return launch_conv_typed<__bf16>(d, a, batch, epi, stream, nf_out);
+  return QVC_ERR_BAD_ARG;
+}
+
+int& post_tail_mode() {
+  static int mode = [] { const char* e = std::getenv("QVC_POST_TAIL"); return e ? std::atoi(e) : 1; }();
+  return mode;
+}
+
+int launch_post_tail(const ConvDesc& d, PostTailArgs a, int batch, int dtype, void* stream) {
+  a.c.Cin = d.Cin; a.c.CinP = d.CinP; a.c.taps = d.taps; a.c.dil = d.dil; a.c.left = d.left;
+  a.c.KS = d.KS(); a.c.nIt = d.nIt(); a.c.nchunk = d.nchunk; a.c.M = d.M;
+  a.c.up_s = d.up_s; a.c.up_p = d.up_p; a.c.Cout = d.Cout;
+  if (dtype == QVC_F16) return launch_post_tail_typed<_Float16>(d, a, batch, stream);
+  if (dtype == QVC_BF16) return launch_post_tail_typed<__bf16>(d, a, batch, stream);
   return QVC_ERR_BAD_ARG;
 }
 

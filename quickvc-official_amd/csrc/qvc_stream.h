@@ -196,8 +196,7 @@ int stream_step(const Plan& P, const char* blob, char* state, char* ws, const fl
     const int spf = samples_per_frame(P);
     Path<Backend> p = make(T, He + G.nf * Hf + Hd1);
     for (int j = 0; j < 3; ++j) p.s0_override[j] = state + S.s0[j];
-    p.dec_back(p.template wsp<float>(p.W.post));
-    p.tail(p.template wsp<float>(p.W.post), reinterpret_cast<float*>(ws + X.wave), nullptr, T * P.total_up + 1);
+    p.dec_back_wave(p.template wsp<float>(p.W.post), reinterpret_cast<float*>(ws + X.wave));
     ok(p.status);
     ok(be.copy2d(out, (size_t)h * spf * 4, ws + X.wave + (size_t)Hd2 * spf * 4, (size_t)T * spf * 4, (size_t)h * spf * 4, (size_t)B));
     const size_t row = (size_t)ch0 * 2;

@@ -254,6 +254,43 @@ def test_persistent_pair_kernel_matches(lib, dev):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_fused_post_tail_matches_two_launches(lib, dev):
+    """conv_post + iSTFT/FIR tail as one launch (the default, qvc_post_tail_impl.h) against QVC_POST_TAIL=0 (conv_post
+    -> fp32 frames in memory -> istft_synth_kernel): same K order in the GEMM, same per-item math in the tail, so the
+    waveforms must agree bit for bit -- whole batch (two utterances, 250 frames: tiles at both ends and in the
+    middle) and a ragged batch (tiles past an utterance's end)."""
+    import subprocess, sys, os, tempfile
+    from helpers import ROOT
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); sys.path.insert(0, %r + '/oracle');\n"
+        "from helpers import load_case, regenerate\n"
+        "import quickvc_official_amd as q\n"
+        "from quickvc_official_amd.engine import QvcEngine\n"
+        "entry, _ = load_case('full_b2'); m, sd, unit, g, noise = regenerate(entry)\n"
+        "res = {}\n"
+        "for dt in ('f16', 'bf16x'):\n"
+        "    eng = QvcEngine(dict(q.SynthesizerTrn(641, 32, **entry['config']).model_config, operand_dtype=dt), sd, torch.device('cuda:0'))\n"
+        "    out, recs = eng.infer_batch_timed(unit.cuda(), g.cuda(), noise.cuda()); torch.cuda.synchronize()\n"
+        "    print('NAMES', dt, sorted(set(r['name'] for r in recs if r['name'].startswith(('post_tail', 'istft')))))\n"
+        "    lens = torch.tensor([unit.shape[2], 77], dtype=torch.int32)\n"
+        "    rag = eng.infer_batch_ragged(unit.cuda(), g.cuda(), noise.cuda(), lens.cuda()); torch.cuda.synchronize()\n"
+        "    res[dt] = (out.cpu(), rag.cpu())\n"
+        "torch.save(res, sys.argv[1])\n") % (ROOT, ROOT, ROOT)
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("1", "0"):
+            path = os.path.join(td, f"o{mode}.pt")
+            res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, QVC_POST_TAIL=mode), capture_output=True,
+                                 text=True, timeout=600)
+            assert res.returncode == 0, res.stderr[-2000:]
+            assert ("post_tail<" in res.stdout) == (mode == "1") and ("istft_synth" in res.stdout) == (mode == "0"), res.stdout
+            outs.append(torch.load(path))
+    for dt in ("f16", "bf16x"):
+        assert torch.equal(outs[0][dt][0], outs[1][dt][0]), dt
+        assert torch.equal(outs[0][dt][1], outs[1][dt][1]), dt
+        assert outs[0][dt][1][1, 0, 320 * 77:].abs().max() == 0 and outs[0][dt][1][1, 0, :320 * 77].abs().max() > 0
+
+
 def test_mixed_bf16x_mode_meets_40_db(lib, dev):
     """operand_dtype="bf16x" (QVC_BF16X): bf16 operands in the WaveNet half (enc_p, flow), f16 in the generator.
     BASELINE.json labels its configs bf16 and asks for >= 40 dB: all-bf16 measures ~34.5 dB on the shipped config
@@ -347,7 +384,7 @@ def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev, monkeypatch):
     torch.cuda.synchronize()
     names = [r["name"] for r in recs]
     assert sum(n.startswith("wn_layer<f16,W12") for n in names) == 32 and not any(n.startswith("wn_stack<") for n in names)
-    assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2 + 1      # + 4 x (pre, post)
+    assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2          # + 4 x (pre, post); conv_post rides in post_tail
     assert snr_db(z_layer.cpu(), z_stack.cpu()) >= 100.0
     assert snr_db(zf_layer.cpu(), zf_stack.cpu()) >= 100.0
 
@@ -380,10 +417,10 @@ def test_timed_variant_reports_every_launch(lib, dev):
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     names = [r["name"] for r in recs]
-    assert names.count("istft_synth") == 1 and names.count("cond_gemv") == 1
-    # enc: pre + proj; dec: conv_pre + 2 ups + conv_post (the coupling layers' pre / post ride in their stack launch);
-    # enc_p WaveNet: 4 launches of 4 layers; 4 coupling stacks; 2 x 9 fused ResBlock pairs
-    assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 1
+    assert names.count("post_tail<f16>") == 1 and names.count("istft_synth") == 0 and names.count("cond_gemv") == 1
+    # enc: pre + proj; dec: conv_pre + 2 ups (the coupling layers' pre / post ride in their stack launch, conv_post in
+    # the tail's); enc_p WaveNet: 4 launches of 4 layers; 4 coupling stacks; 2 x 9 fused ResBlock pairs
+    assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2
     assert sum(n.startswith("wn_stack<") for n in names) == 8 and sum(n.startswith("wn_layer<") for n in names) == 0
     assert sum(n.startswith("rbpair") for n in names) in (6, 12, 18)   # per stage: 3 launches of three chains, or 9 of one
     assert all(r["ms"] >= 0 for r in recs) and sum(r["flops"] for r in recs) > 0
@@ -556,7 +593,7 @@ def test_wide_config_takes_the_fallback_paths(lib, dev):
     names = [r["name"] for r in recs]
     assert sum(n.startswith("rbpair") for n in names) in (3, 9)         # stage 2 (208 channels) still fuses
     assert sum(n.startswith("wn_stack<f16,W16") for n in names) == 8
-    assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 1 + 18   # + 9 x (conv1, conv2) of stage 1
+    assert sum(n.startswith("conv<") for n in names) == 2 + 1 + 2 + 18       # + 9 x (conv1, conv2) of stage 1
     for b in range(2):
         assert snr_db(ref[b], out[b].cpu()) >= 45.0
 

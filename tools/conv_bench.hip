@@ -100,7 +100,10 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us_ = ms * 1e3 / reps;
       const double flops = 2.0 * B * u.T * (double)u.Cin * u.Cout * u.k;
-      printf("%-16s MF%d WM%d NF%-2d chunks%d %8.1f us  %7.1f TF\n", u.name, d.MF, d.WM, nf, d.nchunk, us_, flops / us_ * 1e-6);
+      uint64_t sum = 0;   // checksum of the output: tile variants (QVC_WIDE_CONV=0/2, QVC_WIDE_NF, QVC_WIDE_CL) must agree bit for bit
+      { std::vector<uint16_t> hy((size_t)B * t_out * u.Cout); CK(hipMemcpy(hy.data(), y16, hy.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < hy.size(); ++i) sum = sum * 1000003u + hy[i]; }
+      printf("%-16s MF%d WM%d NF%-3d chunks%d %8.1f us  %7.1f TF  sum %016llx\n", u.name, d.MF, d.WM, nf, d.nchunk, us_, flops / us_ * 1e-6, (unsigned long long)sum);
       CK(hipFree(dw));
     }
   }

@@ -36,6 +36,9 @@ def pretty(name):
     m = re.search(r"conv_mfma_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"conv<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)},{'gau' if m.group(5) == '1' else 'std'}>"
+    m = re.search(r"post_tail_kernelI(DF16_|DF16b)Li(\d+)E", name)
+    if m:
+        return f"post_tail<{'f16' if m.group(1) == 'DF16_' else 'bf16'}>"
     m = re.search(r"wn_stack_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"wn_stack<{'f16' if m.group(1) == 'DF16_' else 'bf16'},W{m.group(4)},L4{',pre+post' if m.group(3) != '0' else ''}>"
