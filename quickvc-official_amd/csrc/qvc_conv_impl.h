@@ -388,14 +388,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
     }
   } else {  // XK_F32_CM: (B, C, T) -- consecutive threads walk along T (coalesced), transposed into the tile
+    // (32 scalar loads in flight per thread: the 32-frame x 256-channel tile of enc_p.pre in ONE memory round trip --
+    //  with 8 it took four dependent ones on an input that comes cold from HBM)
+    constexpr int kCM = 32;
     const float* xb = static_cast<const float*>(a.x) + (size_t)b * a.x_bs;
     const float slope = a.slope_in;
     const int total = R * a.CinP;
-    for (int base = tid; base < total; base += 256 * kU * 2) {
-      float v[kU * 2];
-      int dst[kU * 2];
+    for (int base = tid; base < total; base += 256 * kCM) {
+      float v[kCM];
+      int dst[kCM];
 #pragma unroll
-      for (int u = 0; u < kU * 2; ++u) {
+      for (int u = 0; u < kCM; ++u) {
         const int idx = base + u * 256;
         const int c = idx / R, r = idx - c * R;
         const int ti = t_base + r;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         dst[u] = idx < total ? r * rowbytes + (((c >> 3) ^ swz(r, sm)) << 4) + (c & 7) * 2 : -1;
       }
 #pragma unroll
-      for (int u = 0; u < kU * 2; ++u)
+      for (int u = 0; u < kCM; ++u)
         if (dst[u] >= 0) *reinterpret_cast<T*>(smem + dst[u]) = O::cvt(lrelu(v[u], slope));
     }
   }

@@ -15,51 +15,91 @@
 namespace qvc {
 
 // ------------------------------------------------------------------ cond GEMV
-// out[b][row] = bias[row] + sum_k w[row][k] * g[b][k].  A workgroup owns kGR rows x the whole batch:
-// the g vectors are staged into LDS once per workgroup ([k][b], so the 32 utterances of one k sit in
-// 32 different banks), each thread owns one (row, utterance) pair and walks k with the weight row read
-// as wave-wide broadcasts.  ~0.1 GFLOP in total: latency-sized, it only has to stay out of the way.
-constexpr int kGR = 8, kGB = 32, kGS = kGB + 1;
-__global__ __launch_bounds__(256) void cond_gemv_kernel(const GemvArgs a) {
-  extern __shared__ float s_g[];                        // [gin][kGS]
+// out[b][row] = bias[row] + sum_k w[row][k] * g[b][k].  A workgroup owns kGR rows x kGB utterances: its weight rows
+// (contiguous in memory) and the g vectors ([k][b], so the 32 utterances of one k sit in 32 different banks) are
+// staged into LDS with ALL loads of a thread in flight at once -- one memory round trip per workgroup -- and each
+// thread then owns one (row, utterance) pair and walks k out of LDS.  ~0.1 GFLOP in total: latency-sized, it only
+// has to stay out of the way.  (Round 1 walked the weight row from global memory, 16 loads at a time: four
+// dependent round trips per workgroup, 16-19 us.)
+constexpr int kGR = 16, kGB = 32, kGS = kGB + 1, kGT = kGR * kGB;
+__global__ __launch_bounds__(kGT) void cond_gemv_kernel(const GemvArgs a) {
+  extern __shared__ float s_gv[];                       // [gin][kGS] g, then [kGR][gin] weights
+  float* s_g = s_gv;
+  float* s_w = s_gv + a.gin * kGS;
   const int tid = threadIdx.x;
   const int r = tid >> 5, bl = tid & 31;
-  const int row = blockIdx.x * kGR + r;
+  const int row0 = blockIdx.x * kGR;
+  const int row = row0 + r;
+  const int wq = (kGR * a.gin) >> 2;                    // float4 pieces of the weight block (gin % 4 == 0)
+  const int wlim = (a.rows - row0 < kGR ? a.rows - row0 : kGR) * (a.gin >> 2);
+  constexpr int kWU = 4, kGU = 16;
   for (int b0 = 0; b0 < a.batch; b0 += kGB) {
     __syncthreads();
-    // coalesced along k, all 32 loads of a thread in flight at once (one element per loop trip cost 32 serialised
-    // round trips -- most of this kernel's 27 us); [k][kGS] keeps the transposing store conflict-free
-    for (int k = tid; k < a.gin; k += 256) {
-      float v[kGB];
+    float4 wv[kWU];
+    if (b0 == 0) {
+      // (gin <= 512, checked by the launcher: kWU * kGT float4 cover the 16 rows)
 #pragma unroll
-      for (int bb = 0; bb < kGB; ++bb) v[bb] = (b0 + bb < a.batch) ? a.g[(size_t)(b0 + bb) * a.gin + k] : 0.f;
+      for (int u = 0; u < kWU; ++u) {
+        const int i = tid + u * kGT;
+        wv[u] = i < wlim ? reinterpret_cast<const float4*>(a.w + (size_t)row0 * a.gin)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const int items = a.gin * kGB;
+    for (int base = tid; base < items; base += kGT * kGU) {
+      float v[kGU];
 #pragma unroll
-      for (int bb = 0; bb < kGB; ++bb) s_g[k * kGS + bb] = v[bb];
+      for (int u = 0; u < kGU; ++u) {                   // coalesced along k
+        const int idx = base + u * kGT;
+        const int bb = idx / a.gin, k = idx - bb * a.gin;
+        v[u] = (idx < items && b0 + bb < a.batch) ? a.g[(size_t)(b0 + bb) * a.gin + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kGU; ++u) {
+        const int idx = base + u * kGT;
+        const int bb = idx / a.gin, k = idx - bb * a.gin;
+        if (idx < items) s_g[k * kGS + bb] = v[u];      // [k][kGS] keeps the transposing store conflict-free
+      }
+    }
+    if (b0 == 0) {
+#pragma unroll
+      for (int u = 0; u < kWU; ++u) {
+        const int i = tid + u * kGT;
+        if (i < wq) reinterpret_cast<float4*>(s_w)[i] = wv[u];
+      }
     }
     __syncthreads();
+    float res = 0.f;
     if (row < a.rows && b0 + bl < a.batch) {
-      const float* wr = a.w + (size_t)row * a.gin;
+      const float* wr = s_w + r * a.gin;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int k = 0;
-      // 16 weight loads in flight per thread: walked one float4 at a time the loop pays a cache round trip per step
-#pragma unroll 16
+#pragma unroll 8
       for (; k + 4 <= a.gin; k += 4) {
         const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
         s0 = fmaf(w4.x, s_g[(k + 0) * kGS + bl], s0); s1 = fmaf(w4.y, s_g[(k + 1) * kGS + bl], s1);
         s2 = fmaf(w4.z, s_g[(k + 2) * kGS + bl], s2); s3 = fmaf(w4.w, s_g[(k + 3) * kGS + bl], s3);
       }
-      for (; k < a.gin; ++k) s0 = fmaf(wr[k], s_g[k * kGS + bl], s0);
-      a.out[(size_t)(b0 + bl) * a.rows + row] = (s0 + s1) + (s2 + s3) + a.bias[row];
+      res = (s0 + s1) + (s2 + s3) + a.bias[row];
+    }
+    // the table is [utterance][row]: through LDS, so that 16 neighbouring lanes store the 16 rows of one utterance
+    // (64 contiguous bytes) instead of every lane a 4-byte piece of a different 26 KB-apart line
+    __syncthreads();                                    // everybody is done reading s_g
+    s_g[bl * (kGR + 1) + r] = res;
+    __syncthreads();
+    {
+      const int ob = tid >> 4, orow = tid & 15;         // kGT = 32 utterances x 16 rows
+      if (row0 + orow < a.rows && b0 + ob < a.batch) a.out[(size_t)(b0 + ob) * a.rows + row0 + orow] = s_g[ob * (kGR + 1) + orow];
     }
   }
 }
 
 int launch_gemv(const GemvArgs& a, void* stream) {
   if (a.rows <= 0) return QVC_OK;
-  if (a.gin % 4 || (size_t)a.gin * kGS * 4 > 160 * 1024) return QVC_ERR_BAD_CONFIG;
+  const size_t lds = ((size_t)a.gin * kGS + (size_t)kGR * a.gin) * 4;
+  if (a.gin % 4 || a.gin > 512 || lds > 160 * 1024) return QVC_ERR_BAD_CONFIG;
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(cond_gemv_kernel))) return QVC_ERR_LAUNCH;
-  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, kGR)), dim3(256), (size_t)a.gin * kGS * 4,
+  hipLaunchKernelGGL(cond_gemv_kernel, dim3((unsigned)ceil_div(a.rows, kGR)), dim3(kGT), lds,
                      static_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
