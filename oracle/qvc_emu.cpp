@@ -166,6 +166,22 @@ struct EmuBackend {
           }
       return;
     }
+    if (epi == EPI_SAMPLE) {   // rows [mu | log sigma] paired like the gate rows; z = mu + noise * exp(log sigma) (models.py:93-94)
+      const int C = a.gau_H, hf = d.MF / 2;
+      for (int chunk = 0; chunk < d.nchunk; ++chunk)
+        for (int wave = 0; wave < d.WM; ++wave)
+         for (int f = 0; f < hf; ++f)
+          for (int i = 0; i < 16; ++i) {
+            const int ch = ((chunk * d.WM + wave) * hf + f) * 16 + i;
+            if (ch >= C) continue;
+            const int pm = ((chunk * d.WM + wave) * d.MF + f) * 16 + i, pl = ((chunk * d.WM + wave) * d.MF + hf + f) * 16 + i;
+            for (int q = 0; q < a.Nq; ++q) {
+              const float mu = acc_[idx(pm, q, a.Nq)] + a.bias[ch], ls = acc_[idx(pl, q, a.Nq)] + a.bias[C + ch];
+              a.y32[(size_t)b * a.y32_bs + (size_t)q * a.y32_ts + ch] = mu + a.noise[(size_t)b * a.noise_bs + (size_t)ch * a.noise_ts + q] * std::exp(ls);
+            }
+          }
+      return;
+    }
     for (int v = 0; v < d.M; ++v) {
       const int ph = d.up_s > 1 ? v / d.Cout : 0, co = d.up_s > 1 ? v % d.Cout : v;
       float bias = a.bias ? a.bias[v] : 0.f;

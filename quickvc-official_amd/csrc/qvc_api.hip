@@ -108,7 +108,7 @@ struct TimedBackend {
     int st = launch_conv(d, a, batch, epi, dtype, stream, &nf);
     mark();
     char name[48];
-    std::snprintf(name, sizeof(name), "conv<%s,MF%d,NF%d,WM%d,%s>", dtype == QVC_F16 ? "f16" : "bf16", d.MF, nf, d.WM, epi == EPI_GAU ? "gau" : "std");
+    std::snprintf(name, sizeof(name), "conv<%s,MF%d,NF%d,WM%d,%s>", dtype == QVC_F16 ? "f16" : "bf16", d.MF, nf, d.WM, epi == EPI_GAU ? "gau" : (epi == EPI_SAMPLE ? "smp" : "std"));
     // algorithmic work: a transposed conv does k MACs per (input frame, ci, co), a conv taps MACs per output
     const double macs = d.up_s > 1 ? (double)batch * a.T_in * d.Cin * d.Cout * (double)d.ksize
                                    : (double)batch * a.Nq * (double)d.M * d.taps * d.Cin;
@@ -116,6 +116,7 @@ struct TimedBackend {
     double out_b = 0;
     const double outs = (double)batch * a.T_out * d.Cout;
     if (epi == EPI_GAU) out_b = (double)batch * a.Nq * a.gau_H * 2;
+    else if (epi == EPI_SAMPLE) out_b = (double)batch * a.Nq * a.gau_H * 8;      // noise in, z out
     else {
       if (a.y32) out_b += outs * 4 * (a.y_accum ? 2 : 1);
       if (a.y16) out_b += outs * 2;

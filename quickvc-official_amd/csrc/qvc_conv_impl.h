@@ -453,6 +453,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
       }
     }
+  } else if constexpr (EPI == EPI_SAMPLE) {
+    // fragments [0, MF/2) = mu rows, [MF/2, MF) = log-sigma rows of the same channels: sample in registers
+    static_assert(EPI != EPI_SAMPLE || MF % 2 == 0, "paired rows");
+    constexpr int HF = MF / 2;
+    const int C = a.gau_H;
+#pragma unroll
+    for (int f = 0; f < HF; ++f) {
+      const int ch0 = ((chunk * WM + wm) * HF + f) * 16 + lq * 4;
+      if (ch0 >= C) continue;
+      const float4 bm = *reinterpret_cast<const float4*>(a.bias + ch0);
+      const float4 bl = *reinterpret_cast<const float4*>(a.bias + C + ch0);
+      const float* nb = a.noise + (size_t)b * a.noise_bs + (size_t)ch0 * a.noise_ts;
+      float* zb = a.y32 + (size_t)b * a.y32_bs + ch0;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = qw + n * 16 + lrow;
+        if (q < a.Nq) {
+          const f32x4 mu = acc[f][n], ls = acc[HF + f][n];
+          const float n0 = nb[q], n1 = nb[(size_t)a.noise_ts + q], n2 = nb[2 * (size_t)a.noise_ts + q], n3 = nb[3 * (size_t)a.noise_ts + q];
+          *reinterpret_cast<float4*>(zb + (size_t)q * a.y32_ts) =
+              make_float4((mu[0] + bm.x) + n0 * expf(ls[0] + bl.x), (mu[1] + bm.y) + n1 * expf(ls[1] + bl.y),
+                          (mu[2] + bm.z) + n2 * expf(ls[2] + bl.z), (mu[3] + bm.w) + n3 * expf(ls[3] + bl.w));
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -1466,6 +1491,15 @@ int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, 
       case 2: return launch_nf<T, 2, 4, EPI_GAU>(d, a, batch, stream, nf_out);
       case 4: return launch_nf<T, 4, 4, EPI_GAU>(d, a, batch, stream, nf_out);
       case 6: return launch_nf<T, 6, 4, EPI_GAU>(d, a, batch, stream, nf_out);
+      default: return QVC_ERR_BAD_CONFIG;
+    }
+  }
+  if (epi == EPI_SAMPLE) {
+    if (d.WM != 4 || !d.gau || !a.noise || !a.y32 || !a.bias) return QVC_ERR_BAD_CONFIG;
+    switch (d.MF) {
+      case 2: return launch_nf<T, 2, 4, EPI_SAMPLE>(d, a, batch, stream, nf_out);
+      case 4: return launch_nf<T, 4, 4, EPI_SAMPLE>(d, a, batch, stream, nf_out);
+      case 6: return launch_nf<T, 6, 4, EPI_SAMPLE>(d, a, batch, stream, nf_out);
       default: return QVC_ERR_BAD_CONFIG;
     }
   }

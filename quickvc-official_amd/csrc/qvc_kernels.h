@@ -73,7 +73,9 @@ struct ConvArgs {
   void* y16 = nullptr; int64_t y16_bs = 0; int32_t y16_ts = 0; float slope_out = 1.f;
   // res/skip split (WN 1x1, modules.py:104-112): rows >= split go to y32b[.. v-split] += val
   float* y32b = nullptr; int32_t split = 0;
-  int32_t gau_H = 0;       // EPI_GAU: hidden size (rows are [tanh | sigmoid])
+  int32_t gau_H = 0;       // EPI_GAU: hidden size (rows are [tanh | sigmoid]); EPI_SAMPLE: inter channels (rows [mu | log sigma])
+  // EPI_SAMPLE: y32[b][q][c] = (mu + bias) + noise[b][c][q] * exp(log sigma + bias), noise in the reference's (B, C, T)
+  const float* noise = nullptr; int64_t noise_bs = 0; int32_t noise_ts = 0;
   Ragged rg;               // per-utterance INPUT length (in T_in units); see Ragged
 };
 

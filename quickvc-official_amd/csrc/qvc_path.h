@@ -135,12 +135,22 @@ struct Path {
       ConvArgs a = args(P.enc_proj);
       a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
       a.Nq = T; a.T_out = T; a.rg = rg(1);
+      if (proj_and_sample(P.enc_proj, a, noise, z_out)) return;
       a.y32 = wsp<float>(W.stats); a.y32_bs = (int64_t)T * 2 * C; a.y32_ts = 2 * C;
       conv(P.enc_proj, a, dtype_wn());
     }
     if (status != QVC_OK) return;
     SampleArgs sa{wsp<float>(W.stats), noise, z_out, B, T, C};
     status = be.sample(sa);
+  }
+  // proj packed with paired [mu | log sigma] rows (make_proj): z = mu + noise * exp(log sigma) in the conv epilogue
+  bool proj_and_sample(const ConvDesc& d, ConvArgs& a, const float* noise, float* z_out) {
+    if (!d.gau) return false;
+    const int C = P.cfg.inter_channels;
+    a.gau_H = C; a.noise = noise; a.noise_bs = (int64_t)C * T; a.noise_ts = T;
+    a.y32 = z_out; a.y32_bs = (int64_t)T * C; a.y32_ts = C;
+    conv(d, a, dtype_wn(), EPI_SAMPLE);
+    return true;
   }
 
   // ---- enc_q (models.py:75-95 with cond = g, :582,617): spec, g, noise -> z
@@ -163,6 +173,7 @@ struct Path {
       ConvArgs a = args(Q.proj, qblob);
       a.x = wsp<float>(W.oacc); a.x_kind = XK_F32_FM; a.x_bs = (int64_t)T * H; a.x_ts = H; a.T_in = T;
       a.Nq = T; a.T_out = T; a.rg = rg(1);
+      if (proj_and_sample(Q.proj, a, noise, z_out)) return;
       a.y32 = wsp<float>(W.stats); a.y32_bs = (int64_t)T * 2 * C; a.y32_ts = 2 * C;
       conv(Q.proj, a, dtype_wn());
     }

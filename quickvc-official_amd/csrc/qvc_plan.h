@@ -27,7 +27,8 @@ inline int pair_weight_dtype(const qvc_config& c) { return c.operand_dtype == QV
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-enum EpiKind : int32_t { EPI_STD = 0, EPI_GAU = 1, EPI_RESSKIP = 2 };
+enum EpiKind : int32_t { EPI_STD = 0, EPI_GAU = 1, EPI_RESSKIP = 2,
+                         EPI_SAMPLE = 3 };   // rows [mu | log sigma] paired like the gate rows: z = mu + noise * exp(log sigma)
 
 // One conv expressed as an implicit GEMM  D[v][q] = sum_{tap,ci} Wv[v][tap][ci] * X[q + tap*dil - left][ci].
 struct ConvDesc {
@@ -249,6 +250,16 @@ inline ConvDesc make_conv(int M, int Cin, int taps, int dil, bool gau = false) {
   return d;
 }
 
+// proj of enc_p / enc_q (h -> 2*inter, 1x1; models.py:73,92): rows [mu | log sigma] in the gate-row pairing, so that
+// a lane holds mu and log sigma of the same channels and the sampling z = mu + noise * exp(log sigma) (models.py:93-94)
+// happens in the conv's epilogue -- the stats tensor is never written.  Falls back to natural rows (+ sample_kernel)
+// for widths the paired-row kernels are not built for.
+inline ConvDesc make_proj(int C, int H) {
+  ConvDesc d = make_conv(2 * C, H, 1, 1, /*gau=*/true);
+  if (d.WM == kWaves && (d.MF == 2 || d.MF == 4 || d.MF == 6)) return d;
+  return make_conv(2 * C, H, 1, 1);
+}
+
 inline ConvDesc make_upconv(int Cin, int Cout, int k, int s, int p) {
   ConvDesc d;
   d.up_s = s; d.up_p = p; d.Cout = Cout; d.M = s * Cout;
@@ -288,7 +299,7 @@ inline Plan build_plan(const qvc_config& c) {
   P.enc_pre = make_conv(H, c.unit_channels, 1, 1); place(P.enc_pre);
   make_wn(P.enc_wn, c.enc_layers);
   P.enc_wn.inbias_off = off; off = align_up(off + (int64_t)c.enc_layers * 2 * H * 4, 256);
-  P.enc_proj = make_conv(2 * C, H, 1, 1); place(P.enc_proj);
+  P.enc_proj = make_proj(C, H); place(P.enc_proj);
   // ---- flow, execution order of reverse=True: Flip, L(n-1), Flip, L(n-2), ...
   int cond_rows = 0;
   bool flipped = false;
@@ -433,7 +444,7 @@ inline EncQPlan build_encq_plan(const qvc_config& c) {
     place(r);
     Q.wn.rs_conv.push_back(r);
   }
-  Q.proj = make_conv(2 * C, H, 1, 1); place(Q.proj);
+  Q.proj = make_proj(C, H); place(Q.proj);
   Q.cond_rows = c.enc_layers * 2 * H;
   Q.cond_w_off = off; off = align_up(off + (int64_t)Q.cond_rows * c.gin_channels * 4, 256);
   Q.cond_b_off = off; off = align_up(off + (int64_t)Q.cond_rows * 4, 256);
