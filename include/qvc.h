@@ -198,7 +198,7 @@ int qvc_infer_batch_ex(const qvc_config* cfg, const void* blob_dev,
  * qvc_infer_batch it is NOT hipGraph-capturable and must not be used in the timed region.
  */
 typedef struct qvc_launch_record {
-  char name[48];        /* e.g. "conv<f16,MF2,NF10,std>", "istft_synth", "cond_gemv", "memset" */
+  char name[48];        /* e.g. "conv<f16,MF4,NF2,WM4,std>", "rbpair<bf16x,MF2,NF10,WM4>", "post_tail<f16>", "cond_gemv" */
   float ms;             /* device time of this launch (HIP events on the stream)                */
   double flops;         /* algorithmic FLOPs (2*MAC) of the launch, 0 for byte movers           */
   double bytes;         /* algorithmic bytes: activations in + out + weights, each counted once */

@@ -25,6 +25,9 @@ def load(d, counter):
     return tot, n
 
 
+EPI = {'1': 'gau', '3': 'smp'}   # EpiKind (qvc_plan.h)
+
+
 def pretty(name):
     m = re.search(r"rbpair_persist_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)E", name)
     if m:
@@ -35,7 +38,7 @@ def pretty(name):
         return f"rbpair<{t},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)}>"
     m = re.search(r"conv_mfma_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
-        return f"conv<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)},{'gau' if m.group(5) == '1' else 'std'}>"
+        return f"conv<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)},{EPI.get(m.group(5), 'std')}>"
     m = re.search(r"post_tail_kernelI(DF16_|DF16b)Li(\d+)E", name)
     if m:
         return f"post_tail<{'f16' if m.group(1) == 'DF16_' else 'bf16'}>"
