@@ -317,7 +317,11 @@ struct Path {
       // One launch for the three chains only where two workgroups share a CU (4-wave layouts).  With one 8-wave
       // workgroup per CU (>= 256 channels) the mixed durations just unbalance the CUs: measured 261 us for the
       // fused launch against 226 us for three launches at stage 1 of the shipped config.
-      const int per_launch = block_waves(st.c1[0]) == kWaves ? NB : 1;
+      // ... unless the launch would leave most CUs empty anyway (batch 1-2: 40-80 workgroups per chain at stage 1):
+      // then the three chains side by side are three times the workgroups in the time of the longest
+      // (batch 1: 3 x 43 us instead of 3 x (19 + 31 + 43) us).
+      const bool few_tiles = (int64_t)B * t_out * NB <= 256 * 32;
+      const int per_launch = (block_waves(st.c1[0]) == kWaves || few_tiles) ? NB : 1;
       if (fused) {
         for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
           // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
