@@ -1154,14 +1154,17 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   constexpr int FW = 1;
   constexpr int NB = NF * 16;                 // frames carried by this workgroup (output tile + halo)
   constexpr int MF = 2 * FW;
-  // the skip sum is only needed for the column fragments that overlap the 32 output frames
-  constexpr int OLO = NF > 3 ? 1 : 0, ON = 3;
+  // NF 3 / 6: 32 output frames per workgroup; NF 2: 16 (tiny batches: twice the workgroups and a third less MFMA
+  // work per layer for the same weight stream -- the workgroups would not fill the chip either way).
+  constexpr int OUTF = NF == 2 ? 16 : kWnOutFrames;
+  // the skip sum is only needed for the column fragments that overlap the output frames
+  constexpr int OLO = NF > 3 ? 1 : 0, ON = NF == 2 ? 2 : 3;
 
   const int tid = threadIdx.x, lane = tid & 63, NTH = blockDim.x;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
-  const int q0 = blockIdx.x * kWnOutFrames;
+  const int q0 = blockIdx.x * OUTF;
   const int Tb = ragged_len(a.rg, b, a.T);    // this utterance occupies rows [Tlo, Tb): x is zero outside at every layer
   const int Tlo = ragged_lo(a.rg, b);
   if (q0 >= Tb) return;
@@ -1233,7 +1236,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       }
       if (n >= OLO && n < OLO + ON) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.accum && ch0 < a.H && q >= q0 && q < q0 + kWnOutFrames && q < Tb)      // continue a previous launch's skip sum
+        if (a.accum && ch0 < a.H && q >= q0 && q < q0 + OUTF && q < Tb)      // continue a previous launch's skip sum
           o = *reinterpret_cast<const float4*>(a.out + (size_t)b * a.bs + (size_t)q * a.H + ch0);
         outr[f][n - OLO] = f32x4{o.x, o.y, o.z, o.w};
       }
@@ -1386,13 +1389,13 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         for (int n = 0; n < ON; ++n) {
           const int q = w0 + (OLO + n) * 16 + lrow;
           zin[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (q >= q0 && q < q0 + kWnOutFrames && q < Tb)
+          if (q >= q0 && q < q0 + OUTF && q < Tb)
             zin[n] = *reinterpret_cast<const float4*>(a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v);
         }
 #pragma unroll
         for (int n = 0; n < ON; ++n) {
           const int q = w0 + (OLO + n) * 16 + lrow;
-          if (q >= q0 && q < q0 + kWnOutFrames && q < Tb) {
+          if (q >= q0 && q < q0 + OUTF && q < Tb) {
             float* p = a.z + (size_t)b * a.z_bs + (size_t)q * a.z_ts + a.post_c0 + v;
             float4 zz = zin[n];
             zz.x += a.post_sign * (qacc[m][n][0] + bq.x); zz.y += a.post_sign * (qacc[m][n][1] + bq.y);
@@ -1412,7 +1415,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
 #pragma unroll
     for (int n = OLO; n < OLO + ON; ++n) {
       const int q = w0 + n * 16 + lrow;
-      if (q >= q0 && q < q0 + kWnOutFrames && q < Tb) {
+      if (q >= q0 && q < q0 + OUTF && q < Tb) {
         const size_t off = (size_t)b * a.bs + (size_t)q * a.H + ch0;
         *reinterpret_cast<float4*>(a.out + off) =
             make_float4(outr[f][n - OLO][0], outr[f][n - OLO][1], outr[f][n - OLO][2], outr[f][n - OLO][3]);
@@ -1451,6 +1454,12 @@ inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* n
     const double work = NT + 0.35 * halo + 24.0;
     const double cost = (double)rounds * bpc * work * (bpc == 1 ? 1.3 : 1.0);
     if (cost < best_cost) { best_cost = cost; best = TileChoice{NF, (int)blocks, lds}; }
+#ifndef QVC_FORCE_NF
+    // latency-sized launch: even the smallest tile gives every workgroup a CU of its own -- take it (each workgroup
+    // streams the same weights whatever its tile, so fewer frames per workgroup is less serial MFMA work behind them;
+    // batch 1, up-sampler 0: 35 -> 22 us)
+    if (i == 0 && blocks <= 256) return best;
+#endif
   }
   return best;
 }
@@ -1695,7 +1704,7 @@ inline int launch_wn_stack_pm(const WnStackArgs& a, int waves, int batch, hipStr
   const size_t lds = (size_t)(NF * 16 + a.taps - 1 + NF * 16) * a.HP * 2;
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, kWnOutFrames), (unsigned)batch), dim3((unsigned)waves * 64), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(a.T, NF == 2 ? 16 : kWnOutFrames), (unsigned)batch), dim3((unsigned)waves * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
@@ -1713,9 +1722,12 @@ template <typename T>
 int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (!wn_stack_ok(din, a.layers)) return QVC_ERR_BAD_CONFIG;
-  const int nf = wn_stack_nf(a.taps, a.layers);
+  int nf = wn_stack_nf(a.taps, a.layers);
   const int pm = a.w_post ? a.post_mf : 0;
   if (pm > 1) return QVC_ERR_BAD_CONFIG;
+  // tiny batches (<= 64 of the 32-frame tiles: a quarter of the CUs): 16-frame tiles, when the halo fits a 32-column window
+  if (nf == 3 && 16 + (a.taps - 1) * a.layers <= 32 && (long)batch * ceil_div(a.T, kWnOutFrames) <= 64)
+    return pm ? launch_wn_stack_wv<T, 2, 1>(a, din.WM, batch, stream) : launch_wn_stack_wv<T, 2, 0>(a, din.WM, batch, stream);
   if (nf == 3) return pm ? launch_wn_stack_wv<T, 3, 1>(a, din.WM, batch, stream) : launch_wn_stack_wv<T, 3, 0>(a, din.WM, batch, stream);
   return pm ? launch_wn_stack_wv<T, 6, 1>(a, din.WM, batch, stream) : launch_wn_stack_wv<T, 6, 0>(a, din.WM, batch, stream);
 }
