@@ -259,7 +259,10 @@ __device__ __forceinline__ void gemm_loop_il(f32x4 (&acc)[MF][NF], const typenam
 }
 
 // WM waves along M, WN = 4/WM along the frames; block tile = [WM*MF*16 rows] x [WN*NF*16 frames].
-template <typename T, int MF, int NF, int WM, int EPI>
+// CL ("chunk loop"): the workgroup stages its tile once and walks all the row chunks itself (grid z = 1) instead of
+// one workgroup per chunk each staging the same tile -- for convs whose staging is the expensive part (up-sampler 1:
+// the mean of three streams) and that still leave >= 2 workgroups per CU.
+template <typename T, int MF, int NF, int WM, int EPI, bool CL = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   using O = Op<T>;
   using frag = typename O::frag;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
-  const int b = blockIdx.y, chunk = blockIdx.z;
+  const int b = blockIdx.y;
   const int q0 = blockIdx.x * NT;
   const int R = NT + (a.taps - 1) * a.dil;
   const int rowbytes = a.CinP * 2;
@@ -414,6 +417,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   __syncthreads();
 
   // ------------------------------------------------------------------ K loop: A from global (ring), B from LDS
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int chunk_lo = CL ? 0 : (int)blockIdx.z, chunk_hi = CL ? a.nchunk : chunk_lo + 1;
+  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
   f32x4 acc[MF][NF];
 #pragma unroll
   for (int m = 0; m < MF; ++m)
@@ -421,7 +427,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const frag* ap = static_cast<const frag*>(a.w) + ((size_t)(chunk * WM + wm) * a.nIt * MF) * 64 + lane;
-  const int lrow = lane & 15, lq = lane >> 4;
   gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
 
   // ------------------------------------------------------------------ epilogue
@@ -479,6 +484,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
   } else {
+  bool packed = false;
+  if constexpr (MF % 2 == 0) if (a.lp) {
+    packed = true;
+    // lane-packed rows (ConvDesc::lp; only a y16 output -- checked by launch_conv): the lane's MF quads are the
+    // 4*MF consecutive virtual rows v0.., all of one phase, stored as MF/2 16-byte pieces per frame
+    const int v0 = (chunk * WM + wm) * MF * 16 + lq * 4 * MF;
+    if (v0 < a.M) {
+      int ph = 0, co = v0;
+      if (a.up_s > 1) { ph = v0 / a.Cout; co = v0 - ph * a.Cout; }
+      float4 bias[MF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        bias[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bias[m] = *reinterpret_cast<const float4*>(a.bias + v0 + m * 4);
+        if (a.bbias) {
+          const float4 bb = *reinterpret_cast<const float4*>(a.bbias + (size_t)b * a.bbias_bs + v0 + m * 4);
+          bias[m].x += bb.x; bias[m].y += bb.y; bias[m].z += bb.z; bias[m].w += bb.w;
+        }
+      }
+      T* yb = static_cast<T*>(a.y16) + (size_t)b * a.y16_bs + co;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int q = qw + n * 16 + lrow;
+        const int o = q * a.up_s + ph - a.up_p;
+        if (q >= a.Nq || o < 0 || o >= a.T_out) continue;
+        frag h[MF / 2];
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          h[m >> 1][(m & 1) * 4 + 0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope_out));
+          h[m >> 1][(m & 1) * 4 + 1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope_out));
+          h[m >> 1][(m & 1) * 4 + 2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope_out));
+          h[m >> 1][(m & 1) * 4 + 3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope_out));
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < MF / 2; ++k2) *reinterpret_cast<frag*>(yb + (size_t)o * a.y16_ts + k2 * 8) = h[k2];
+      }
+    }
+  }
+  if (!packed) {
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       const int v = ((chunk * WM + wm) * MF + m) * 16 + lq * 4;
@@ -533,6 +577,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
   }
+  }
+  }   // chunk
 }
 
 
@@ -1464,15 +1510,27 @@ inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* n
   return best;
 }
 
-template <typename T, int MF, int NF, int WM, int EPI>
-inline int launch_one(const ConvArgs& a, int batch, size_t lds, hipStream_t stream) {
-  auto kern = conv_mfma_kernel<T, MF, NF, WM, EPI>;
+template <typename T, int MF, int NF, int WM, int EPI, bool CL = false>
+inline int launch_one_cl(const ConvArgs& a, int batch, size_t lds, hipStream_t stream) {
+  auto kern = conv_mfma_kernel<T, MF, NF, WM, EPI, CL>;
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   constexpr int NT = (kWaves / WM) * NF * 16;
-  dim3 grid((unsigned)ceil_div(a.Nq, NT), (unsigned)batch, (unsigned)a.nchunk);
+  dim3 grid((unsigned)ceil_div(a.Nq, NT), (unsigned)batch, (unsigned)(CL ? 1 : a.nchunk));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+template <typename T, int MF, int NF, int WM, int EPI>
+inline int launch_one(const ConvArgs& a, int batch, size_t lds, hipStream_t stream) {
+  // chunk loop: built for the 4 x 4-fragment layout; taken when the tile is the mean of three streams (expensive to
+  // stage) and the launch still has two workgroups for every CU without the chunk dimension
+  if constexpr (EPI == EPI_STD && MF == 4 && WM == 4 && NF <= 5) {
+    constexpr int NT = (kWaves / WM) * NF * 16;
+    static const int mode = [] { const char* e = getenv("QVC_CONV_CL"); return e ? atoi(e) : 1; }();   // developer switch
+    if (mode && a.nchunk >= 2 && a.x2 && (long)ceil_div(a.Nq, NT) * batch >= 512)
+      return launch_one_cl<T, MF, NF, WM, EPI, true>(a, batch, lds, stream);
+  }
+  return launch_one_cl<T, MF, NF, WM, EPI, false>(a, batch, lds, stream);
 }
 
 template <typename T, int MF, int WM, int EPI>

@@ -266,6 +266,9 @@ inline ConvDesc make_upconv(int Cin, int Cout, int k, int s, int p) {
   d.Cin = Cin; d.CinP = (int)align_up(Cin, kKStep);
   d.taps = ceil_div(k, s); d.ksize = k; d.dil = 1; d.left = d.taps - 1;
   choose_mf(d);
+  // lane-packed rows (as in the fused pairs): a lane's MF quads are 4*MF consecutive channels of ONE phase, so the
+  // polyphase scatter stores 8*MF bytes per lane and frame -- whole 128-byte lines per 4 lanes instead of 32-byte pieces
+  if (d.MF % 2 == 0 && Cout % (4 * d.MF) == 0) d.lp = 1;
   return d;
 }
 
