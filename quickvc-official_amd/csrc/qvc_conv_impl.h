@@ -427,7 +427,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const frag* ap = static_cast<const frag*>(a.w) + ((size_t)(chunk * WM + wm) * a.nIt * MF) * 64 + lane;
-  gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
+  // Polyphase rows: phase ph of a transposed conv (kernel k, stride s) has ceil((k - ph) / s) real taps; the packed
+  // stream pads every phase to `taps` with zero weights, and with left = taps - 1 those zeros are the FIRST taps.
+  // This wave's rows start in phase ph0 (the phase with the most taps among them): skip the k-steps all of its rows
+  // have zeros in (k 16, s 5: 3 real taps out of 4 for four of the five phases -- a fifth of the up-sampler's work).
+  int it0 = 0;
+  if (a.up_s > 1 && a.ksize > 0) {
+    const int ph0 = ((chunk * WM + wm) * MF * 16) / a.Cout;
+    const int real = ph0 < a.up_s ? (a.ksize - ph0 + a.up_s - 1) / a.up_s : 0;
+    const int tap0 = a.taps - (real < a.taps ? real : a.taps);
+    it0 = tap0 * a.KS;
+  }
+  gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap + (size_t)it0 * MF * 64, a.nIt - it0, a.KS, a.dil, smem, rowbytes, sm,
+                                    wn * (NF * 16) + lrow + (it0 / a.KS) * a.dil, lq, QVC_ROT(a.nIt));
 
   // ------------------------------------------------------------------ epilogue
   const int qw = q0 + wn * (NF * 16);                           // first frame of this wave's columns

@@ -76,6 +76,7 @@ struct ConvArgs {
   int32_t gau_H = 0;       // EPI_GAU: hidden size (rows are [tanh | sigmoid]); EPI_SAMPLE: inter channels (rows [mu | log sigma])
   // EPI_SAMPLE: y32[b][q][c] = (mu + bias) + noise[b][c][q] * exp(log sigma + bias), noise in the reference's (B, C, T)
   const float* noise = nullptr; int64_t noise_bs = 0; int32_t noise_ts = 0;
+  int32_t ksize = 0;       // polyphase (up_s > 1): kernel size of the transposed conv -- phases with fewer real taps skip their zero ones
   int32_t lp = 0;          // ConvDesc::lp (lane-packed rows): EPI_STD with only a y16 output (the polyphase up-samplers)
   Ragged rg;               // per-utterance INPUT length (in T_in units); see Ragged
 };

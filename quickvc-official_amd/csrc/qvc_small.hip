@@ -250,7 +250,7 @@ int launch_fm_to_cm(const float* src, float* dst, int batch, int frames, int cha
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out) {
   a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left;
   a.KS = d.KS(); a.nIt = d.nIt(); a.nchunk = d.nchunk; a.M = d.M;
-  a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout; a.lp = d.lp;
+  a.up_s = d.up_s; a.up_p = d.up_p; a.Cout = d.Cout; a.lp = d.lp; a.ksize = d.ksize;
   if (d.lp && (epi != EPI_STD || !a.y16 || a.y32 || a.y32b || a.res || a.res16 || d.MF % 2)) return QVC_ERR_BAD_CONFIG;
   if (dtype == QVC_F16) return launch_conv_typed<_Float16>(d, a, batch, epi, stream, nf_out);
   if (dtype == QVC_BF16) return launch_conv_typed<__bf16>(d, a, batch, epi, stream, nf_out);
