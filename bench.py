@@ -169,7 +169,9 @@ def main() -> None:
         # when that hash matches the sources of THIS run and the file names the dominant kernel; otherwise null.
         traffic, traffic_source = None, "no PMC file for these kernel sources (run tools/profile_bench.sh)"
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tpath):
+        if args.batch != BATCH:
+            traffic_source = f"the PMC file is for batch {BATCH} per GPU (bytes per launch scale with the batch)"
+        elif os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel_source_sha1") != kernel_source_sha1():
