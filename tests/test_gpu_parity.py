@@ -598,6 +598,43 @@ def test_wide_config_takes_the_fallback_paths(lib, dev):
         assert snr_db(ref[b], out[b].cpu()) >= 45.0
 
 
+@pytest.mark.parametrize("name,over", [
+    # other widths: proj rows pair up at 2 fragments per wave, up-sampler rows stay in natural order at stage 1
+    ("narrow", dict(inter_channels=128, hidden_channels=96, upsample_initial_channel=256, gin_channels=128)),
+    # other up-sampling geometry (x4, x4: a phase count that divides the kernel size on one stage only) and ResBlocks
+    ("x4x4", dict(upsample_rates=[4, 4], upsample_kernel_sizes=[15, 16], resblock_kernel_sizes=[3, 5, 7],
+                  resblock_dilation_sizes=[[1, 2, 3], [1, 2, 3], [1, 2, 3]], upsample_initial_channel=384)),
+    # multi-band decoder: fixed PQMF synthesis instead of the learned FIR (models.py:250-279, pqmf.py:106-117)
+    ("multiband", dict(ms_istft_vits=False, mb_istft_vits=True, upsample_initial_channel=256, inter_channels=96, hidden_channels=128)),
+])
+def test_other_configurations_vs_oracle(lib, dev, name, over):
+    """Configurations the goldens do not cover, against the CPU oracle (no golden: the reference was not run on
+    them): every fusion this path takes by default -- paired proj rows with the sampling epilogue, lane-packed
+    up-samplers with skipped zero taps, conv_post + tail in one launch, three chains per launch -- has to fall back or
+    re-shape itself correctly when channel counts, up-sampling rates and kernel sizes change."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd.engine import QvcEngine
+    from quickvc_official_amd.synth import make_synthetic_state_dict, make_synthetic_inputs
+    cfg = dict(q.DEFAULT_MODEL_CONFIG, **over)
+    model = q.SynthesizerTrn(641, 32, **cfg)
+    sd = make_synthetic_state_dict(model, 311)
+    B, T = 3, 41
+    unit, g, noise = make_synthetic_inputs(B, T, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=71)
+    ref = oracle.infer_from_g(sd, cfg, unit, g.unsqueeze(-1), noise)
+    for dt, min_db in (("f16", 45.0), ("bf16x", 38.0)):
+        eng = QvcEngine(dict(model.model_config, operand_dtype=dt), sd, dev)
+        out = eng.infer_batch(unit.to(dev), g.to(dev), noise.to(dev))
+        lens = torch.tensor([T, 17, 30], dtype=torch.int32)
+        rag = eng.infer_batch_ragged(unit.to(dev), g.to(dev), noise.to(dev), lens.to(dev))
+        torch.cuda.synchronize()
+        spf = eng.samples_per_frame
+        assert out.shape == (B, 1, T * spf)
+        for b in range(B):
+            assert snr_db(ref[b], out[b].cpu()) >= min_db, (name, dt, b)
+        assert torch.equal(rag[0], out[0])                      # full-length member of the ragged batch == the plain batch
+        assert rag[1, 0, 17 * spf:].abs().max() == 0 and rag[1, 0, :17 * spf].abs().max() > 0
+
+
 # ------------------------------------------------------------------ speaker encoder (SURVEY 8f #1)
 def _g_err(ref, got):
     ref, got = np.asarray(ref, np.float64), np.asarray(got, np.float64)
