@@ -634,8 +634,8 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
   const int nj = A.n;
-  const int chain = nj > 1 ? (int)(blockIdx.x % (unsigned)nj) : 0;
-  const int q0 = (nj > 1 ? (int)(blockIdx.x / (unsigned)nj) : (int)blockIdx.x) * NT;
+  const int chain = nj > 1 ? (A.chain_major ? (int)blockIdx.z : (int)(blockIdx.x % (unsigned)nj)) : 0;
+  const int q0 = ((nj > 1 && !A.chain_major) ? (int)(blockIdx.x / (unsigned)nj) : (int)blockIdx.x) * NT;
   PairArgs a = A.p[0];                   // scalar selects: a dynamic index into the kernel arguments would go through scratch
   if (chain == 1) a = A.p[1];
   if (chain == 2) a = A.p[2];
@@ -1633,7 +1633,9 @@ inline int launch_pair_one(const PairArgs3& a, int batch, size_t lds, hipStream_
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
   constexpr int NT = (NWV / WM) * NF * 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(ceil_div(a.p[0].T, NT) * a.n), (unsigned)batch), dim3(NWV * 64), lds, stream, a);
+  const unsigned tiles = (unsigned)ceil_div(a.p[0].T, NT);
+  const dim3 grid = a.chain_major ? dim3(tiles, (unsigned)batch, (unsigned)a.n) : dim3(tiles * (unsigned)a.n, (unsigned)batch, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 

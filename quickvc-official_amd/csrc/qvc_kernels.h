@@ -100,6 +100,10 @@ struct PairArgs3 {
   PairArgs p[3];
   int32_t n = 1;
   Ragged rg;               // per-utterance length (in T units), shared by the chains
+  // 1: chain = blockIdx.z (grid tiles x batch x n): all workgroups of the first chain are dispatched before the second
+  //    chain's -- the one-workgroup-per-CU layouts, where the launch then behaves like n launches back to back without
+  //    the gaps between them; 0: chain = blockIdx.x % n (chains interleaved on the CUs)
+  int32_t chain_major = 0;
 };
 
 // One fused WaveNet layer (modules.py:87-112): k-tap conv h->2h + conditioning + tanh*sigmoid gate, then the

@@ -16,6 +16,7 @@
 //                      void wait_branch_done(int j); void join(int n);   (stream fork/join; no-ops on one stream)
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include "qvc_kernels.h"
 
 namespace qvc {
@@ -314,19 +315,23 @@ struct Path {
           const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
           fused = fused && pair_supported(d1, d2) && d1.lp && d2.lp && d1.MF == st.c1[0].MF && d1.WM == st.c1[0].WM;
         }
-      // One launch for the three chains only where two workgroups share a CU (4-wave layouts).  With one 8-wave
-      // workgroup per CU (>= 256 channels) the mixed durations just unbalance the CUs: measured 261 us for the
-      // fused launch against 226 us for three launches at stage 1 of the shipped config.
-      // ... unless the launch would leave most CUs empty anyway (batch 1-2: 40-80 workgroups per chain at stage 1):
-      // then the three chains side by side are three times the workgroups in the time of the longest
-      // (batch 1: 3 x 43 us instead of 3 x (19 + 31 + 43) us).
+      // One launch for the three chains.  Where two workgroups share a CU (4-wave layouts) the chains are interleaved
+      // on the CUs (x % n).  With one 8-wave workgroup per CU (>= 256 channels) interleaving just unbalances the CUs
+      // (261 us against 226 us for three launches at stage 1 of the shipped config), so the grid is chain-major there:
+      // all workgroups of the longest chain are dispatched first and the others backfill -- three launches' work
+      // without the gaps between them (636 -> 597 us for the nine stage-1 pairs).  Tiny batches (40-80 workgroups
+      // per chain) interleave again: everything runs at once, in the time of the longest chain (batch 1: 3 x 43 us
+      // instead of 3 x (19 + 31 + 43) us).
       const bool few_tiles = (int64_t)B * t_out * NB <= 256 * 32;
-      const int per_launch = (block_waves(st.c1[0]) == kWaves || few_tiles) ? NB : 1;
+      const bool wide = block_waves(st.c1[0]) != kWaves;
+      static const int wide_mode = [] { const char* e = getenv("QVC_PAIR_WIDE_LAUNCH"); return e ? atoi(e) : 1; }();   // 0: one chain per launch
+      const int per_launch = (!wide || few_tiles || wide_mode) ? NB : 1;
+      const int chain_major = (wide && !few_tiles) ? 1 : 0;
       if (fused) {
         for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
           // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
           // consumer (next up-sampler / conv_post) while it stages its input, so nothing is accumulated here
-          PairArgs3 a3; a3.n = per_launch; a3.rg = rg(rate);
+          PairArgs3 a3; a3.n = per_launch; a3.rg = rg(rate); a3.chain_major = per_launch > 1 ? chain_major : 0;
           ConvDesc d1s[3], d2s[3];
           // the chain with the largest kernel first: its workgroups are the longest, so they should start earliest
           int order[3] = {j0, j0 + 1, j0 + 2};
