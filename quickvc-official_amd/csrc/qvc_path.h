@@ -315,18 +315,20 @@ struct Path {
           const ConvDesc& d2 = st.c2[(size_t)j * 3 + q];
           fused = fused && pair_supported(d1, d2) && d1.lp && d2.lp && d1.MF == st.c1[0].MF && d1.WM == st.c1[0].WM;
         }
-      // One launch for the three chains.  Where two workgroups share a CU (4-wave layouts) the chains are interleaved
-      // on the CUs (x % n).  With one 8-wave workgroup per CU (>= 256 channels) interleaving just unbalances the CUs
-      // (261 us against 226 us for three launches at stage 1 of the shipped config), so the grid is chain-major there:
-      // all workgroups of the longest chain are dispatched first and the others backfill -- three launches' work
-      // without the gaps between them (636 -> 597 us for the nine stage-1 pairs).  Tiny batches (40-80 workgroups
-      // per chain) interleave again: everything runs at once, in the time of the longest chain (batch 1: 3 x 43 us
-      // instead of 3 x (19 + 31 + 43) us).
+      // One launch for the three chains, chain-major grid (blockIdx.z = chain, longest kernel first): the dispatcher
+      // hands out all workgroups of the k 11 chain first and the shorter chains backfill the CUs as they free up --
+      // longest-processing-time-first, so the launch ends on short workgroups.  Interleaving the chains on the CUs
+      // (x % n) left long workgroups for the end: with one 8-wave workgroup per CU (stage 1) 261 us against 226 us for
+      // three launches and 199 us chain-major; with two 4-wave workgroups per CU (stage 2) chain-major takes another
+      // 45 us off the step (2.11 -> 2.065 ms, same box, alternating runs).  Tiny batches (40-80 workgroups per
+      // chain) interleave: everything runs at once, in the time of the longest chain (batch 1: 3 x 43 us instead of
+      // 3 x (19 + 31 + 43) us).
       const bool few_tiles = (int64_t)B * t_out * NB <= 256 * 32;
       const bool wide = block_waves(st.c1[0]) != kWaves;
       static const int wide_mode = [] { const char* e = getenv("QVC_PAIR_WIDE_LAUNCH"); return e ? atoi(e) : 1; }();   // 0: one chain per launch
       const int per_launch = (!wide || few_tiles || wide_mode) ? NB : 1;
-      const int chain_major = (wide && !few_tiles) ? 1 : 0;
+      static const int cm4 = [] { const char* e = getenv("QVC_PAIR_CM4"); return e ? atoi(e) : 1; }();   // 0: interleave the chains of 4-wave layouts (x % n)
+      const int chain_major = ((wide || cm4) && !few_tiles) ? 1 : 0;
       if (fused) {
         for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
           // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
