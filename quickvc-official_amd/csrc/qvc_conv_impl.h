@@ -635,7 +635,8 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   const int b = blockIdx.y;
   const int nj = A.n;
   const int chain = nj > 1 ? (A.chain_major ? (int)blockIdx.z : (int)(blockIdx.x % (unsigned)nj)) : 0;
-  const int q0 = ((nj > 1 && !A.chain_major) ? (int)(blockIdx.x / (unsigned)nj) : (int)blockIdx.x) * NT;
+  const int tile = (nj > 1 && !A.chain_major) ? (int)(blockIdx.x / (unsigned)nj) : (int)blockIdx.x;
+  const int q0 = tile * NT;
   PairArgs a = A.p[0];                   // scalar selects: a dynamic index into the kernel arguments would go through scratch
   if (chain == 1) a = A.p[1];
   if (chain == 2) a = A.p[2];
