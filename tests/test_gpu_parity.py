@@ -277,17 +277,23 @@ def test_fused_post_tail_matches_two_launches(lib, dev):
         "    res[dt] = (out.cpu(), rag.cpu())\n"
         "torch.save(res, sys.argv[1])\n") % (ROOT, ROOT, ROOT)
     outs = []
+    # third run: the launch shapes of earlier rounds -- chains interleaved on the CUs, one chain per launch at stage 1,
+    # one workgroup per row chunk in up-sampler 1: where a workgroup runs must not change a bit
+    variants = ({"QVC_POST_TAIL": "1"}, {"QVC_POST_TAIL": "0"},
+                {"QVC_POST_TAIL": "1", "QVC_PAIR_CM4": "0", "QVC_PAIR_WIDE_LAUNCH": "0", "QVC_CONV_CL": "0"})
     with tempfile.TemporaryDirectory() as td:
-        for mode in ("1", "0"):
-            path = os.path.join(td, f"o{mode}.pt")
-            res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, QVC_POST_TAIL=mode), capture_output=True,
+        for i, extra in enumerate(variants):
+            path = os.path.join(td, f"o{i}.pt")
+            res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), capture_output=True,
                                  text=True, timeout=600)
             assert res.returncode == 0, res.stderr[-2000:]
-            assert ("post_tail<" in res.stdout) == (mode == "1") and ("istft_synth" in res.stdout) == (mode == "0"), res.stdout
+            fusedtail = extra["QVC_POST_TAIL"] == "1"
+            assert ("post_tail<" in res.stdout) == fusedtail and ("istft_synth" in res.stdout) == (not fusedtail), res.stdout
             outs.append(torch.load(path))
     for dt in ("f16", "bf16x"):
-        assert torch.equal(outs[0][dt][0], outs[1][dt][0]), dt
-        assert torch.equal(outs[0][dt][1], outs[1][dt][1]), dt
+        for other in (1, 2):
+            assert torch.equal(outs[0][dt][0], outs[other][dt][0]), (dt, other)
+            assert torch.equal(outs[0][dt][1], outs[other][dt][1]), (dt, other)
         assert outs[0][dt][1][1, 0, 320 * 77:].abs().max() == 0 and outs[0][dt][1][1, 0, :320 * 77].abs().max() > 0
 
 
