@@ -593,6 +593,28 @@ int qvc_emu_speaker_embed(const qvc_config* cfg, const void* spk_blob, const flo
 
 // Stage taps for debugging: copies frame-major fp32 buffers out of the workspace after a run.
 // which: 0 = z (after flow), 1 = post (conv_post output), 2 = stage-0 MRF mean, 3 = stage-1 MRF mean
+// Layout decisions of the plan for `cfg` (test hook: the shipped configuration must actually take the fast paths):
+// out[0] enc_p.proj rows paired [mu | log sigma] (sampling in the epilogue), out[1] its fragments per wave,
+// out[2..3] up-samplers 0 / 1 lane-packed, out[4] conv_post + tail can run as one launch,
+// out[5..6] waves per workgroup of the stage 0 / 1 ResBlock pairs, out[7] all pairs fusable
+int qvc_emu_plan_flags(const qvc_config* cfg, int32_t* out) {
+  if (!cfg || !out) return QVC_ERR_BAD_ARG;
+  const Plan P = build_plan(*cfg);
+  if (P.status != QVC_OK) return P.status;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  out[0] = P.enc_proj.gau; out[1] = P.enc_proj.MF;
+  for (size_t i = 0; i < P.stages.size() && i < 2; ++i) {
+    out[2 + i] = P.stages[i].up.lp;
+    out[5 + i] = block_waves(P.stages[i].c1[0]);
+  }
+  out[4] = post_tail_supported(P.conv_post) ? 1 : 0;
+  int all = 1;
+  for (const StagePlan& st : P.stages)
+    for (size_t j = 0; j < st.c1.size(); ++j) all = all && pair_supported(st.c1[j], st.c2[j]) && st.c1[j].lp;
+  out[7] = all;
+  return QVC_OK;
+}
+
 int64_t qvc_emu_tap_offset(const qvc_config* cfg, int32_t batch, int32_t frames, int32_t which) {
   Plan P = build_plan(*cfg);
   if (P.status != QVC_OK) return P.status;

@@ -30,6 +30,8 @@ def load_emu():
     lib.qvc_emu_flow_forward.argtypes = [P(L.QvcConfig), V, V, V, I, I, V, Lg]
     lib.qvc_emu_tap_offset.restype = Lg
     lib.qvc_emu_tap_offset.argtypes = [P(L.QvcConfig), I, I, I]
+    lib.qvc_emu_plan_flags.restype = ctypes.c_int
+    lib.qvc_emu_plan_flags.argtypes = [P(L.QvcConfig), P(I)]
     return lib
 
 

@@ -441,3 +441,25 @@ def test_frontend_and_cli_planning():
     if os.path.exists(ref):                                         # container only: the reference's own demo input
         w = F.load_wav(ref, 16000)
         assert w.dtype == np.float32 and abs(len(w) - 26007) <= 1 and np.abs(w).max() <= 1.0
+
+
+def test_shipped_configuration_takes_the_fast_paths(built):
+    """The plan for the shipped model configuration must select every fused / repacked layout the measured numbers
+    rest on -- a silent fall-back (natural rows, separate launches) would still be correct, only slower: proj with
+    paired [mu | log sigma] rows (sampling in its epilogue), lane-packed up-samplers, conv_post + tail as one launch,
+    fused ResBlock pairs with 4 waves per workgroup at 128 channels and 8 at 256."""
+    import quickvc_official_amd as q
+    from quickvc_official_amd import lib as L
+    import emu
+    emulib = emu.load_emu()
+    for dt in ("f16", "bf16", "bf16x"):
+        cfg = L.make_config(dict(q.SynthesizerTrn(641, 32, **q.DEFAULT_MODEL_CONFIG).model_config, operand_dtype=dt))
+        out = (ctypes.c_int32 * 8)()
+        assert emulib.qvc_emu_plan_flags(ctypes.byref(cfg), out) == 0
+        assert list(out) == [1, 6, 1, 1, 1, 8, 4, 1], (dt, list(out))
+    # a narrow configuration keeps natural up-sampler rows where a lane's channels would straddle two phases
+    cfg = L.make_config(dict(q.SynthesizerTrn(641, 32, **q.MINI_MODEL_CONFIG).model_config))
+    out = (ctypes.c_int32 * 8)()
+    assert emulib.qvc_emu_plan_flags(ctypes.byref(cfg), out) == 0
+    assert out[0] == 1 and out[4] == 1 and out[7] == 1
+
