@@ -14,7 +14,10 @@
  *   - every function returns an int status: 0 = QVC_OK, negative = error
  *     (qvc_status_string() names it).  Nothing throws, aborts or prints.
  *   - device pointers are raw HIP device addresses owned by the caller
- *     (tensor.data_ptr()); the library allocates nothing and keeps no global state.
+ *     (tensor.data_ptr()); the library allocates nothing and keeps no global state
+ *     (two exceptions, neither reachable from the environment: a per-device flag that
+ *     remembers the one-time opt-in to > 64 KiB of LDS, and the developer switches of
+ *     qvc_debug_set(), which start at their production values).
  *   - all device work is enqueued asynchronously on the caller's hipStream_t
  *     (passed as void*); no host sync, no allocation, no host read inside, so
  *     every call is hipGraph-capturable.  Thread-safe by statelessness.
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define QVC_ABI_VERSION 7
+#define QVC_ABI_VERSION 8
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -111,6 +114,13 @@ const char* qvc_status_string(int status);
 /* 0 when a gfx950 device is visible to this process, QVC_ERR_NO_DEVICE otherwise. */
 int qvc_device_check(void);
 
+/* Developer / test switches (launch-shape and kernel-selection variants that must give identical results; the GPU
+ * tests flip them in-process).  The library never reads environment variables: a switch changes only through this
+ * call.  Names: "post_tail", "post_tail_nf", "pair_wide_launch", "pair_cm4", "conv_cl", "wn_chunk", "pair_chain3",
+ * "wn_kernel".  Unknown name: QVC_ERR_BAD_ARG.  No reference counterpart. */
+int qvc_debug_set(const char* name, int32_t value);
+int qvc_debug_get(const char* name, int32_t* value);
+
 /* ---- weights: replaces nn.Module.load_state_dict + per-forward weight_norm ----
  * Reference: utils.py:148-180 (load), modules.py:54,64,67,134-143 and
  * models.py:327,333,346,357 (weight_norm recomputed every forward).  Folds
@@ -151,6 +161,14 @@ int qvc_infer_batch_ragged(const qvc_config* cfg, const void* blob_dev,
                            const float* unit, const float* g, const float* noise, float* out,
                            int32_t batch, int32_t max_frames, const int32_t* frames_dev,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with the units as they are ON DISK: dataset/encode.py:33-38 saves each utterance's HuBERT-soft units as a
+ * (frames, 256) float32 .npy, data_utils_new_new.py:121-122 transposes after loading.  unit_fm is [B][max_frames][256]
+ * (frame-major, row b padded to max_frames; padding content ignored), so a batch of files can be read straight into
+ * the upload buffer (include/qvc_io.h) with no host-side transpose. */
+int qvc_infer_batch_ragged_fm(const qvc_config* cfg, const void* blob_dev,
+                              const float* unit_fm, const float* g, const float* noise, float* out,
+                              int32_t batch, int32_t max_frames, const int32_t* frames_dev,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- streaming: one hop of new unit frames per call, state in a caller-owned buffer (BASELINE configs[4]) -----
  * The reference converts whole utterances; every op of the path is a bounded, symmetric
@@ -176,6 +194,13 @@ int qvc_stream_step(const qvc_config* cfg, const void* blob_dev, void* state, in
                     const float* unit_new, const float* g, const float* noise_new, float* out,
                     int32_t batch, int32_t hop, const int32_t* pos_dev, const int32_t* len_dev,
                     void* workspace, int64_t workspace_bytes, void* stream);
+/* Admit a NEW stream into slot `slot` of a running batch (a server whose streams start and end at different times):
+ * zeroes that slot's rows of every ring in `state` and sets pos_dev[slot] = 0, len_dev[slot] = length (a large number
+ * while unknown) on `stream`.  The other slots are untouched, a captured step graph is replayed unchanged (it only
+ * holds pointers), and the caller copies the new stream's g row itself.  Ending a stream = writing its length into
+ * len_dev[slot]; the slot is free again once pos - lag >= length.  No reference counterpart. */
+int qvc_stream_reset_slot(const qvc_config* cfg, void* state, int64_t state_bytes, int32_t batch, int32_t hop,
+                          int32_t slot, int32_t length, int32_t* pos_dev, int32_t* len_dev, void* stream);
 
 /* ---- optional fork/join resources: lets the three independent ResBlocks of an MRF stage
  * (models.py:378-384) run as parallel branches (two auxiliary non-blocking streams + events), so a

@@ -22,8 +22,8 @@ EMU_LIB = os.path.join(EMU_DIR, "libqvc_emu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["qvc_conv_f16.hip", "qvc_conv_bf16.hip", "qvc_small.hip", "qvc_spk.hip", "qvc_mel.hip", "qvc_api.hip", "qvc_pack.cpp"]
-HEADERS = ["qvc_plan.h", "qvc_kernels.h", "qvc_conv_impl.h", "qvc_post_tail_impl.h", "qvc_tail_impl.h", "qvc_path.h", "qvc_stream.h", "qvc_pack_util.h", "qvc_launch_util.h"]
+SOURCES = ["qvc_conv_f16.hip", "qvc_conv_bf16.hip", "qvc_wn2.hip", "qvc_small.hip", "qvc_spk.hip", "qvc_mel.hip", "qvc_api.hip", "qvc_pack.cpp"]
+HEADERS = ["qvc_plan.h", "qvc_kernels.h", "qvc_conv_impl.h", "qvc_wn2_impl.h", "qvc_post_tail_impl.h", "qvc_tail_impl.h", "qvc_path.h", "qvc_stream.h", "qvc_pack_util.h", "qvc_launch_util.h"]
 
 
 def _newer(target: str, deps) -> bool:

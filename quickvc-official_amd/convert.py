@@ -91,14 +91,14 @@ def main(argv=None) -> None:
     p.add_argument("--batch", type=int, default=32)
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x"])
+    p.add_argument("--device", type=int, default=None, help="GPU ordinal (default: LOCAL_RANK); rehearsals of several ranks on one GPU pass 0")
     args = p.parse_args(argv)
 
     from scipy.io.wavfile import write
     os.makedirs(args.outdir, exist_ok=True)
     hps = get_hparams_from_file(args.hpfile)
     rank, local_rank, world = env_world()
-    # QVC_CLI_REHEARSAL=1 (never set in production): every rank on cuda:0, to rehearse the sharded run on a one-GPU box
-    torch.cuda.set_device(0 if os.environ.get("QVC_CLI_REHEARSAL") == "1" else local_rank)
+    torch.cuda.set_device(local_rank if args.device is None else args.device)
     print("Loading model...")
     net_g = SynthesizerTrn(hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
                            **hps.model, operand_dtype=args.dtype).cuda().eval()

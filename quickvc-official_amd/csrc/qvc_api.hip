@@ -25,12 +25,11 @@ struct qvc_aux {
 namespace {
 using namespace qvc;
 
-// Layers per whole-stack WaveNet launch.  QVC_WN_CHUNK overrides it (tuning runs; -1 = no stack kernel at all:
-// one fused launch per layer and the coupling layers' pre / post as separate convs -- the path taken by
+// Layers per whole-stack WaveNet launch.  The debug switch "wn_chunk" overrides it (tuning runs; -1 = no stack kernel
+// at all: one fused launch per layer and the coupling layers' pre / post as separate convs -- the path taken by
 // configurations the stack kernel does not cover, selectable so that the tests can exercise it).
 inline int wn_chunk(int layers) {
-  const char* e = std::getenv("QVC_WN_CHUNK");
-  const int env = e ? std::atoi(e) : 0;
+  const int env = debug_get(DBG_WN_CHUNK);
   if (env < 0) return 0;
   if (env > 0) return env <= layers ? env : layers;
   return layers % 4 == 0 ? 4 : layers;
@@ -81,7 +80,7 @@ struct HipBackend {
   int gemv(const GemvArgs& a) { return launch_gemv(a, stream); }
   int sample(const SampleArgs& a) { return launch_sample(a, stream); }
   int tail(const TailArgs& a) { return launch_tail(a, stream); }
-  bool post_tail_ok(const ConvDesc& d) const { return post_tail_mode() != 0 && post_tail_supported(d); }
+  bool post_tail_ok(const ConvDesc& d) const { return debug_get(DBG_POST_TAIL) != 0 && post_tail_supported(d); }
   int post_tail(const ConvDesc& d, const PostTailArgs& a, int batch, int dtype) { return launch_post_tail(d, a, batch, dtype, stream); }
   int zero(void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; }
   int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
@@ -169,8 +168,8 @@ struct TimedBackend {
     int st = launch_wn_stack(din, a, batch, dtype, stream);
     mark();
     char name[48];
-    std::snprintf(name, sizeof(name), "wn_stack<%s,W%d,L%d%s>", dtype == QVC_F16 ? "f16" : "bf16", din.WM, a.layers,
-                  dpre ? ",pre+post" : "");
+    std::snprintf(name, sizeof(name), "%s<%s,W%d,L%d%s>", wn_stack_variant(din, a) == 2 ? "wn_stack2" : "wn_stack", dtype == QVC_F16 ? "f16" : "bf16",
+                  din.WM, a.layers, dpre ? ",pre+post" : "");
     const double cols = (double)batch * a.T;
     const double fl = 2.0 * cols * a.H * (a.layers * 2.0 * a.H * a.taps + (a.layers - (a.final_layer ? 1 : 0)) * (double)drs.M + (a.final_layer ? (double)drs_last.M : 0.0));
     const double fuse_fl = (dpre ? 2.0 * cols * dpre->M * dpre->Cin : 0.0) + (dpost ? 2.0 * cols * dpost->M * dpost->Cin : 0.0);
@@ -183,7 +182,7 @@ struct TimedBackend {
     note("sample", 0, (double)a.batch * a.frames * a.C * 16); return st; }
   int tail(const TailArgs& a) { if (ev.empty()) mark(); int st = launch_tail(a, stream); mark();
     note("istft_synth", 0, (double)a.batch * ((double)a.F * 72 * 4 + 16.0 * (a.F - 1) * 4)); return st; }
-  bool post_tail_ok(const ConvDesc& d) const { return post_tail_mode() != 0 && post_tail_supported(d); }
+  bool post_tail_ok(const ConvDesc& d) const { return debug_get(DBG_POST_TAIL) != 0 && post_tail_supported(d); }
   int post_tail(const ConvDesc& d, const PostTailArgs& a, int batch, int dtype) {
     if (ev.empty()) mark();
     int st = launch_post_tail(d, a, batch, dtype, stream);
@@ -219,6 +218,25 @@ int check_common(const qvc_config* cfg, const void* blob, int batch, int frames,
   return QVC_OK;
 }
 
+// qvc_infer_batch_ragged / _fm: the whole path over utterances of different lengths (unit_fm: units frame-major as on disk)
+int infer_ragged(const qvc_config* cfg, const void* blob_dev, const float* unit, bool unit_fm, const float* g, const float* noise,
+                 float* out, int32_t batch, int32_t max_frames, const int32_t* frames_dev, void* workspace, int64_t workspace_bytes,
+                 void* stream) {
+  if (!unit || !g || !noise || !out || !frames_dev) return QVC_ERR_BAD_ARG;
+  Plan P; Workspace W;
+  int st = check_common(cfg, blob_dev, batch, max_frames, workspace, workspace_bytes, P, W);
+  if (st != QVC_OK) return st;
+  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
+  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, max_frames, be};
+  c.lens = frames_dev;
+  c.unit_fm = unit_fm;
+  c.cond_table(g);
+  c.enc_p(unit, noise, c.wsp<float>(W.z));
+  c.flow(c.wsp<float>(W.z));
+  c.dec_trunk_wave(c.wsp<float>(W.z), c.wsp<float>(W.post), out);
+  return c.status != QVC_OK ? c.status : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,6 +255,20 @@ const char* qvc_status_string(int status) {
     case QVC_ERR_NO_DEVICE: return "no gfx950 HIP device visible";
     default: return "unknown status";
   }
+}
+
+int qvc_debug_set(const char* name, int32_t value) {
+  if (!name) return QVC_ERR_BAD_ARG;
+  for (int i = 0; i < DBG_COUNT; ++i)
+    if (std::strcmp(name, debug_names()[i]) == 0) { debug_table()[i].store(value, std::memory_order_relaxed); return QVC_OK; }
+  return QVC_ERR_BAD_ARG;
+}
+
+int qvc_debug_get(const char* name, int32_t* value) {
+  if (!name || !value) return QVC_ERR_BAD_ARG;
+  for (int i = 0; i < DBG_COUNT; ++i)
+    if (std::strcmp(name, debug_names()[i]) == 0) { *value = debug_get(i); return QVC_OK; }
+  return QVC_ERR_BAD_ARG;
 }
 
 int qvc_device_check(void) {
@@ -303,18 +335,13 @@ int qvc_infer_batch_ex(const qvc_config* cfg, const void* blob_dev, const float*
 int qvc_infer_batch_ragged(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,
                            const float* noise, float* out, int32_t batch, int32_t max_frames, const int32_t* frames_dev,
                            void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!unit || !g || !noise || !out || !frames_dev) return QVC_ERR_BAD_ARG;
-  Plan P; Workspace W;
-  int st = check_common(cfg, blob_dev, batch, max_frames, workspace, workspace_bytes, P, W);
-  if (st != QVC_OK) return st;
-  HipBackend be; be.stream = be.stream0 = static_cast<hipStream_t>(stream);
-  Ctx c{P, static_cast<const char*>(blob_dev), static_cast<char*>(workspace), W, batch, max_frames, be};
-  c.lens = frames_dev;
-  c.cond_table(g);
-  c.enc_p(unit, noise, c.wsp<float>(W.z));
-  c.flow(c.wsp<float>(W.z));
-  c.dec_trunk_wave(c.wsp<float>(W.z), c.wsp<float>(W.post), out);
-  return c.status != QVC_OK ? c.status : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
+  return infer_ragged(cfg, blob_dev, unit, false, g, noise, out, batch, max_frames, frames_dev, workspace, workspace_bytes, stream);
+}
+
+int qvc_infer_batch_ragged_fm(const qvc_config* cfg, const void* blob_dev, const float* unit_fm, const float* g,
+                              const float* noise, float* out, int32_t batch, int32_t max_frames, const int32_t* frames_dev,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  return infer_ragged(cfg, blob_dev, unit_fm, true, g, noise, out, batch, max_frames, frames_dev, workspace, workspace_bytes, stream);
 }
 
 int64_t qvc_stream_state_bytes(const qvc_config* cfg, int32_t batch, int32_t hop) {
@@ -362,6 +389,31 @@ int qvc_stream_step(const qvc_config* cfg, const void* blob_dev, void* state, in
   const int st = stream_step(P, static_cast<const char*>(blob_dev), static_cast<char*>(state), static_cast<char*>(workspace), unit_new, g,
                              noise_new, out, batch, hop, pos_dev, len_dev, be);
   return st != QVC_OK ? st : (be.br.ok ? QVC_OK : QVC_ERR_LAUNCH);
+}
+
+int qvc_stream_reset_slot(const qvc_config* cfg, void* state, int64_t state_bytes, int32_t batch, int32_t hop, int32_t slot,
+                          int32_t length, int32_t* pos_dev, int32_t* len_dev, void* stream) {
+  if (!cfg || !state || !pos_dev || !len_dev || batch <= 0 || hop <= 0 || slot < 0 || slot >= batch || length < 0) return QVC_ERR_BAD_ARG;
+  Plan P = build_plan(*cfg);
+  const StreamGeom G = stream_geom(P, hop);
+  if (G.status != QVC_OK) return G.status;
+  const StreamState S = carve_stream_state(P, G, batch);
+  if (state_bytes < S.bytes) return QVC_ERR_SMALL_BUFFER;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(state);
+  const qvc_config& c = P.cfg;
+  bool ok = true;
+  // every ring is batch-major, so a stream's rows are one contiguous range per ring
+  auto zero = [&](int64_t ring, int64_t per_stream) {
+    ok = ok && hipMemsetAsync(base + ring + (int64_t)slot * per_stream, 0, (size_t)per_stream, st) == hipSuccess;
+  };
+  zero(S.unit, (int64_t)c.unit_channels * (2 * G.He + G.hop) * 4);
+  for (int k = 0; k < G.nf; ++k) zero(S.zf[k], (int64_t)(2 * G.Hf + G.hop) * c.inter_channels * 4);
+  zero(S.zd, (int64_t)(2 * G.Hd1 + G.hop) * c.inter_channels * 4);
+  for (int j = 0; j < 3; ++j) zero(S.s0[j], (int64_t)(2 * G.Hd2 + G.hop) * G.r0 * P.stages[0].ch * 2);
+  ok = ok && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pos_dev + slot), 0, 1, st) == hipSuccess;
+  ok = ok && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(len_dev + slot), length, 1, st) == hipSuccess;   // no host buffer involved
+  return ok ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
 int qvc_infer_batch_timed(const qvc_config* cfg, const void* blob_dev, const float* unit, const float* g,

@@ -111,6 +111,13 @@ __device__ __forceinline__ f16x8 lrelu8<_Float16>(f16x8 v, float slope) {
 #else
 #define QVC_ABL(bit) 0
 #endif
+// developer phase stamps for tools/conv_bench (never defined in the product build): s_memtime at the phase boundaries of
+// the WaveNet stack kernel, written to WnStackArgs::stamps [workgroup][wave][32] at the end of the kernel
+#ifdef QVC_STAMP
+#define QVC_ST(slot) (st_[slot] = __builtin_amdgcn_s_memtime())
+#else
+#define QVC_ST(slot) ((void)0)
+#endif
 #ifndef QVC_PF_WN
 #define QVC_PF_WN 3
 #endif
@@ -193,69 +200,6 @@ __device__ __forceinline__ void gemm_loop(f32x4 (&acc)[MF][NF], const typename O
   typename Op<T>::frag ar[kPF + 1][MF];
   gemm_prime<T, MF, kPF, AS>(ar, ap, nIt);
   gemm_loop_primed<T, MF, NF, kPF, AS>(acc, ar, ap, nIt, KS, dil, tile, rowbytes, sm, colrow, lq);
-}
-
-// The K loop for ONE WAVE PER SIMD (persistent pair kernel).  With a partner wave on the SIMD the loop above is
-// fine: while one wave issues its loads the other's MFMAs keep the pipe busy.  Alone, the ~45 load / address
-// instructions of a k-step would sit between two MFMA clusters with the matrix pipe idle.  Here every step is one
-// straight-line block -- loads are unconditional (the prefetch index and the tap wrap around instead of being
-// skipped at the tail, so they stay in bounds) -- and sched_group_barrier lays it out as
-//   MF MFMAs, the MF weight loads, then (one LDS read, MF MFMAs) ...
-// so each 16-cycle MFMA covers the issue of the next load.  RB = compile-time row pitch in bytes (0: runtime), which
-// turns the NF fragment addresses of a step into immediate offsets of one base register.
-template <typename T, int MF, int NF, int kPF, int RB>
-__device__ __forceinline__ void gemm_loop_il(f32x4 (&acc)[MF][NF], const typename Op<T>::frag* ap, int nIt, int KS, int taps, int dil,
-                                             const char* tile, int rowbytes_rt, Swz sm, int colrow, int lq) {
-  using O = Op<T>;
-  using frag = typename O::frag;
-  constexpr int RING = kPF + 1;
-  static_assert(RING % 2 == 0, "the B double buffer needs an even ring");
-  const int rowbytes = RB ? RB : rowbytes_rt;
-  frag ar[RING][MF];
-  frag bf[2][NF];
-  const int last = nIt - 1;
-#pragma unroll
-  for (int u = 0; u < kPF; ++u) {
-    const int idx = u < last ? u : last;
-#pragma unroll
-    for (int m = 0; m < MF; ++m) ar[u][m] = ap[((size_t)idx * MF + m) * 64];
-  }
-  int pf = kPF;
-  int tap = 0, ks = 0;
-  auto read_b = [&](frag (&dst)[NF]) {
-    const int row0 = tap * dil + colrow;
-    const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
-#pragma unroll
-    for (int n = 0; n < NF; ++n) dst[n] = *reinterpret_cast<const frag*>(bp + n * 16 * rowbytes);
-    if (++ks == KS) { ks = 0; if (++tap == taps) tap = 0; }
-  };
-  read_b(bf[0]);
-  for (int it0 = 0; it0 < nIt; it0 += RING) {
-#pragma unroll
-    for (int u = 0; u < RING; ++u) {
-      if (it0 + u < nIt) {                                          // wave-uniform
-        const int pfi = pf < last ? pf : last;
-        ++pf;
-        if (!QVC_ABL(5)) {
-#pragma unroll
-          for (int m = 0; m < MF; ++m) ar[(u + kPF) % RING][m] = ap[((size_t)pfi * MF + m) * 64];
-        }
-        if (!QVC_ABL(6)) read_b(bf[(u + 1) & 1]);
-#pragma unroll
-        for (int n = 0; n < NF; ++n)
-#pragma unroll
-          for (int m = 0; m < MF; ++m) acc[m][n] = O::mfma(ar[u][m], bf[u & 1][n], acc[m][n]);
-        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);         // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, MF, 0);         // VMEM read (weights)
-#pragma unroll
-        for (int n = 0; n < NF - 1; ++n) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one LDS read ...
-          __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);       // ... under MF MFMAs
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    }
-  }
 }
 
 // WM waves along M, WN = 4/WM along the frames; block tile = [WM*MF*16 rows] x [WN*NF*16 frames].
@@ -826,231 +770,6 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 }
 
 
-// ------------------------------------------------------------------ persistent fused ResBlock1 pair
-// The same math as rbpair_kernel, restructured so that NO memory phase is exposed ("pair kernel"):
-//   * one 4-wave workgroup per CU (one wave per SIMD, up to 512 registers each) walks a static list of tiles
-//     (chain, utterance, 16*NF frames);
-//   * the NEXT tile's rows are fetched into registers while GEMM2 of the current tile runs (issue early, write to
-//     LDS late) -- the CU's vector-memory path returns data in order, so loads that miss to HBM delay every later
-//     L2-hit weight load of the CU; the weight ring is therefore kPFA k-steps deep (about 2 us of MFMA work), which
-//     rides through an HBM round trip, instead of the 3 k-steps that cover an L2 hit;
-//   * the raw residual rows of the tile stay in a second LDS region, so x is read from memory exactly once and
-//     the epilogue is acc + bias + LDS residual -> 16-byte stores, which drain under the next tile's GEMM1.
-// Barriers are raw s_barrier + lgkmcnt(0): they order LDS traffic and leave global loads / stores in flight.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
-
-constexpr int kPairPFA = 11;             // A-fragment prefetch depth of the persistent pair kernel (k-steps)
-
-template <typename T, int MF, int NF, int PFU, int RB>
-__global__ __launch_bounds__(256, 1) void rbpair_persist_kernel(const PairArgs3 A, const int tiles, const int batch, const int tile_rows) {
-  using O = Op<T>;
-  using frag = typename O::frag;
-  using quad = typename O::quad;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NTHR = 256;
-  constexpr int NF1 = NF + 1;
-  constexpr int NT = NF * 16;            // output frames per tile
-  constexpr int N1P = NF1 * 16;          // intermediate frames computed per tile (>= NT + 2*h2)
-  constexpr bool kWide = MF % 2 == 0;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lrow = lane & 15, lq = lane >> 4;
-  const int CP = RB ? RB / 2 : A.p[0].CP, C = A.p[0].C, Tpad = A.p[0].T;
-  const int rowbytes = CP * 2;
-  const int cpr = CP >> 3;
-  const Swz sm = swz_mode(cpr);
-  char* tileb = smem;                                  // activated input tile / intermediate tile
-  char* resb = smem + (size_t)tile_rows * rowbytes;    // raw residual rows of the current tile [NT]
-  const int cb = wm * MF * 16 + lq * 4 * MF;           // first of this lane's 4*MF consecutive channels
-  const int per_chain = tiles * batch;
-  const int items = A.n * per_chain;
-  const int rstep = NTHR / cpr, cstep = NTHR - rstep * cpr;
-  const int r_0 = tid / cpr, c_0 = tid - r_0 * cpr;
-
-  // item -> (chain arguments, utterance, first frame); scalar selects, no dynamic index into the kernel arguments
-  auto decode = [&](int it, PairArgs& a, int& b, int& q0) {
-    const int chain = it / per_chain, rem = it - chain * per_chain;
-    b = rem / tiles;
-    q0 = (rem - b * tiles) * NT;
-    a = A.p[0];
-    if (chain == 1) a = A.p[1];
-    if (chain == 2) a = A.p[2];
-  };
-
-  uint4 pf[PFU];                                       // the next tile on its way from memory to LDS
-  // Loads are unconditional from a clamped (always valid) address and the out-of-range rows are zeroed when the
-  // tile is written: a conditional load per element would put an exec-mask branch around each of them.
-  auto issue_loads = [&](const PairArgs& a, int b, int q0) {
-    const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
-    const int t_base = q0 - h2 - h1;
-    const int T_ = Tpad;                               // clamped addresses only need to stay inside the buffer
-    const T* xb = static_cast<const T*>(a.x) + (size_t)b * a.bs;
-    const int cmax = (C >> 3) - 1;
-    int r = r_0, c8 = c_0;
-#pragma unroll
-    for (int u = 0; u < PFU; ++u) {
-      const int ti = min(max(t_base + r, 0), T_ - 1);
-      if (QVC_ABL(0)) pf[u] = make_uint4(0x3c003c00u, 0xbc00bc00u, 0x3c003c00u, 0xbc00bc00u);
-      else pf[u] = *reinterpret_cast<const uint4*>(xb + (ti * C + min(c8, cmax) * 8));
-      c8 += cstep; r += rstep;
-      if (c8 >= cpr) { c8 -= cpr; ++r; }
-    }
-  };
-  auto write_tile = [&](const PairArgs& a, int b, int q0) {
-    const int T_ = ragged_len(A.rg, b, Tpad);          // rows past the utterance's end are zeros (ragged batches)
-    const int h2 = (a.k - 1) / 2, h1 = h2 * a.dil;
-    const int total = (N1P + 2 * h1) * cpr;
-    const int t_base = q0 - h2 - h1;
-    int r = r_0, c8 = c_0;
-#pragma unroll
-    for (int u = 0; u < PFU; ++u) {
-      const int idx = tid + u * NTHR;
-      if (idx < total) {
-        const int ti = t_base + r;
-        uint4 raw = pf[u];
-        if (ti < ragged_lo(A.rg, b) || ti >= T_ || c8 * 8 >= C) raw = make_uint4(0u, 0u, 0u, 0u);
-        frag h; __builtin_memcpy(&h, &raw, 16);
-        *reinterpret_cast<frag*>(tileb + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = lrelu8<T>(h, a.slope);
-        const int rr = r - h1 - h2;                    // tile row of frame q0 is h1 + h2
-        if (rr >= 0 && rr < NT) *reinterpret_cast<uint4*>(resb + rr * rowbytes + ((c8 ^ swz(rr, sm)) << 4)) = raw;
-      }
-      c8 += cstep; r += rstep;
-      if (c8 >= cpr) { c8 -= cpr; ++r; }
-    }
-  };
-
-  int it = blockIdx.x;
-  if (it >= items) return;
-  PairArgs a; int b, q0;
-  decode(it, a, b, q0);
-  issue_loads(a, b, q0);
-  write_tile(a, b, q0);
-  lds_barrier();
-
-  for (;;) {
-    const int T_ = ragged_len(A.rg, b, Tpad);
-    const int nxt = it + gridDim.x;
-    const bool has_next = nxt < items;                 // wave-uniform (scalar)
-    {   // ---- GEMM1 over N1P frames, then bias + lrelu -> intermediate tile (in place of the input tile)
-      f32x4 acc[MF][NF1];
-#pragma unroll
-      for (int m = 0; m < MF; ++m)
-#pragma unroll
-        for (int n = 0; n < NF1; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const frag* ap = static_cast<const frag*>(a.w1) + ((size_t)wm * a.nIt * MF) * 64 + lane;
-      if (!QVC_ABL(1)) gemm_loop_il<T, MF, NF1, kPairPFA, RB>(acc, ap, a.nIt, a.KS, a.k, a.dil, tileb, rowbytes, sm, lrow, lq);
-      float4 bias[MF];
-#pragma unroll
-      for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b1 + cb + m * 4);
-      const int h2 = (a.k - 1) / 2;
-      lds_barrier();                                   // every wave is done reading the input tile
-#pragma unroll
-      for (int n = 0; n < NF1; ++n) {
-        const int jr = n * 16 + lrow;                  // intermediate row <-> frame q0 - h2 + jr
-        const int f = q0 - h2 + jr;
-        const bool inside = f >= ragged_lo(A.rg, b) && f < T_;   // conv2 zero-pads outside the utterance
-        char* rowp = tileb + jr * rowbytes;
-        const int sw = swz(jr, sm);
-        if constexpr (kWide) {
-#pragma unroll
-          for (int m = 0; m < MF; m += 2) {
-            const int v = cb + m * 4;
-            if (v >= CP) continue;
-            frag h;
-            if (inside && v < C) {
-              h[0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope));
-              h[2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope));
-              h[4] = O::cvt(lrelu(acc[m + 1][n][0] + bias[m + 1].x, a.slope)); h[5] = O::cvt(lrelu(acc[m + 1][n][1] + bias[m + 1].y, a.slope));
-              h[6] = O::cvt(lrelu(acc[m + 1][n][2] + bias[m + 1].z, a.slope)); h[7] = O::cvt(lrelu(acc[m + 1][n][3] + bias[m + 1].w, a.slope));
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) h[e] = (T)0.f;
-            }
-            *reinterpret_cast<frag*>(rowp + (((v >> 3) ^ sw) << 4)) = h;
-          }
-        } else {
-#pragma unroll
-          for (int m = 0; m < MF; ++m) {
-            const int v = cb + m * 4;
-            if (v >= CP) continue;
-            quad h;
-            if (inside && v < C) {
-              h[0] = O::cvt(lrelu(acc[m][n][0] + bias[m].x, a.slope)); h[1] = O::cvt(lrelu(acc[m][n][1] + bias[m].y, a.slope));
-              h[2] = O::cvt(lrelu(acc[m][n][2] + bias[m].z, a.slope)); h[3] = O::cvt(lrelu(acc[m][n][3] + bias[m].w, a.slope));
-            } else {
-              h[0] = h[1] = h[2] = h[3] = (T)0.f;
-            }
-            *reinterpret_cast<quad*>(rowp + (((v >> 3) ^ sw) << 4) + (v & 7) * 2) = h;
-          }
-        }
-      }
-    }
-    lds_barrier();
-
-    if (has_next) {                                    // the next tile starts its trip from memory under GEMM2
-      PairArgs an; int bn, q0n;                        // (decoded again after GEMM2: cheaper than holding them in SGPRs)
-      decode(nxt, an, bn, q0n);
-      issue_loads(an, bn, q0n);
-    }
-
-    {   // ---- GEMM2 over NT frames (dilation 1) + bias + residual (from LDS) -> y
-      f32x4 acc[MF][NF];
-#pragma unroll
-      for (int m = 0; m < MF; ++m)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
-      if (!QVC_ABL(2)) gemm_loop_il<T, MF, NF, kPairPFA, RB>(acc, ap, a.nIt, a.KS, a.k, 1, tileb, rowbytes, sm, lrow, lq);
-      float4 bias[MF];
-#pragma unroll
-      for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b2 + cb + m * 4);
-      T* yb = static_cast<T*>(a.y) + (size_t)b * a.bs;
-#pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        const int jr = n * 16 + lrow;
-        const int q = q0 + jr;
-        const char* rrow = resb + jr * rowbytes;
-        const int sw = swz(jr, sm);
-        if constexpr (kWide) {
-#pragma unroll
-          for (int m = 0; m < MF; m += 2) {
-            const int v = cb + m * 4;
-            if (v >= C || q >= T_) continue;
-            const frag r8 = *reinterpret_cast<const frag*>(rrow + (((v >> 3) ^ sw) << 4));
-            frag h;
-            h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
-            h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r8[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r8[3]);
-            h[4] = O::cvt(acc[m + 1][n][0] + bias[m + 1].x + (float)r8[4]); h[5] = O::cvt(acc[m + 1][n][1] + bias[m + 1].y + (float)r8[5]);
-            h[6] = O::cvt(acc[m + 1][n][2] + bias[m + 1].z + (float)r8[6]); h[7] = O::cvt(acc[m + 1][n][3] + bias[m + 1].w + (float)r8[7]);
-            if (!QVC_ABL(3) || h[0] == (T)12345.f) *reinterpret_cast<frag*>(yb + (size_t)q * C + v) = h;
-          }
-        } else {
-#pragma unroll
-          for (int m = 0; m < MF; ++m) {
-            const int v = cb + m * 4;
-            if (v >= C || q >= T_) continue;
-            const quad r4 = *reinterpret_cast<const quad*>(rrow + (((v >> 3) ^ sw) << 4) + (v & 7) * 2);
-            quad h;
-            h[0] = O::cvt(acc[m][n][0] + bias[m].x + (float)r4[0]); h[1] = O::cvt(acc[m][n][1] + bias[m].y + (float)r4[1]);
-            h[2] = O::cvt(acc[m][n][2] + bias[m].z + (float)r4[2]); h[3] = O::cvt(acc[m][n][3] + bias[m].w + (float)r4[3]);
-            *reinterpret_cast<quad*>(yb + (size_t)q * C + v) = h;
-          }
-        }
-      }
-    }
-    if (!has_next) break;
-    lds_barrier();                                     // every wave is done with the intermediate and the residual rows
-    it = nxt;
-    decode(it, a, b, q0);
-    write_tile(a, b, q0);
-    lds_barrier();
-  }
-}
-
 // ------------------------------------------------------------------ fused WaveNet layer
 // One wave per 16 channels (blockDim = HP/16 waves <= WV, see wn_layout in qvc_plan.h): wave w holds the tanh,
 // sigmoid, res and skip rows of channels [16w, 16w+16), so one workgroup owns ALL 2h gate rows of its NF*16
@@ -1224,6 +943,11 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * OUTF;
+#ifdef QVC_STAMP
+  unsigned long long st_[32] = {};
+  st_[27] = __builtin_amdgcn_s_memrealtime();
+#endif
+  QVC_ST(0);
   const int Tb = ragged_len(a.rg, b, a.T);    // this utterance occupies rows [Tlo, Tb): x is zero outside at every layer
   const int Tlo = ragged_lo(a.rg, b);
   if (q0 >= Tb) return;
@@ -1318,6 +1042,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   };
   put_x();
   __syncthreads();
+  QVC_ST(1);
 
   for (int l = 0; l < a.layers; ++l) {
     const bool last = a.final_layer && l == a.layers - 1;      // the network's last layer has no residual half
@@ -1329,6 +1054,9 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       const frag* ap = static_cast<const frag*>(a.w_in[l]) + ((size_t)wm * a.nIt1 * MF) * 64 + lane;
       if (!QVC_ABL(1)) gemm_loop<T, MF, NF, QVC_PF_STACK>(acc, ap, a.nIt1, a.KS, 1, smem, rowbytes, sm, lrow, lq, 0);
+#ifdef QVC_STAMP
+      if (l < 4) QVC_ST(2 + 6 * l);
+#endif
       const float* bb = a.bbias + (size_t)b * a.bbias_bs + (size_t)l * 2 * a.H;
 #pragma unroll
       for (int f = 0; f < FW; ++f) {
@@ -1355,7 +1083,13 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         }
       }
     }
+#ifdef QVC_STAMP
+    if (l < 4) QVC_ST(3 + 6 * l);
+#endif
     __syncthreads();                          // acts complete; every wave is done reading the x tile
+#ifdef QVC_STAMP
+    if (l < 4) QVC_ST(4 + 6 * l);
+#endif
     {   // ---- GEMM2 (1x1): x += res, out += skip   (modules.py:104-112)
       f32x4 acc[MF][NF];
 #pragma unroll
@@ -1366,6 +1100,9 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       if (!last) {
         const frag* ap = static_cast<const frag*>(a.w_rs[l]) + ((size_t)wm * a.KS * MF) * 64 + lane;
         if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_STACK>(acc, ap, a.KS, a.KS, 1, acts, rowbytes, sm, lrow, lq, 0);
+#ifdef QVC_STAMP
+        if (l < 4) QVC_ST(5 + 6 * l);
+#endif
 #pragma unroll
         for (int f = 0; f < FW; ++f) {
           const int ch0 = (wm * FW + f) * 16 + lq * 4;
@@ -1406,7 +1143,13 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         }
       }
     }
+#ifdef QVC_STAMP
+    if (l < 4) QVC_ST(6 + 6 * l);
+#endif
     __syncthreads();                          // x tile updated / acts tile free for the next layer
+#ifdef QVC_STAMP
+    if (l < 4) QVC_ST(7 + 6 * l);
+#endif
   }
 
   if constexpr (PM > 0) {
@@ -1482,6 +1225,15 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
       }
     }
   }
+#ifdef QVC_STAMP
+  QVC_ST(26);
+  st_[28] = __builtin_amdgcn_s_memrealtime();
+  if (a.stamps && lane == 0) {
+    unsigned long long* dst = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wm) * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dst[i] = st_[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ launch-side tile selection
@@ -1539,8 +1291,7 @@ inline int launch_one(const ConvArgs& a, int batch, size_t lds, hipStream_t stre
   // stage) and the launch still has two workgroups for every CU without the chunk dimension
   if constexpr (EPI == EPI_STD && MF == 4 && WM == 4 && NF <= 5) {
     constexpr int NT = (kWaves / WM) * NF * 16;
-    static const int mode = [] { const char* e = getenv("QVC_CONV_CL"); return e ? atoi(e) : 1; }();   // developer switch
-    if (mode && a.nchunk >= 2 && a.x2 && (long)ceil_div(a.Nq, NT) * batch >= 512)
+    if (debug_get(DBG_CONV_CL) && a.nchunk >= 2 && a.x2 && (long)ceil_div(a.Nq, NT) * batch >= 512)
       return launch_one_cl<T, MF, NF, WM, EPI, true>(a, batch, lds, stream);
   }
   return launch_one_cl<T, MF, NF, WM, EPI, false>(a, batch, lds, stream);
@@ -1655,64 +1406,10 @@ inline int launch_pair_nf(const ConvDesc* ds, const PairArgs3& a, int batch, hip
   return QVC_ERR_BAD_CONFIG;
 }
 
-// ---- persistent pair kernel: one workgroup per CU walks the tile list (see rbpair_persist_kernel)
-inline int device_cu_count() {
-  static std::atomic<int> cached[32] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  int n = cached[dev & 31].load(std::memory_order_relaxed);
-  if (n > 0) return n;
-  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
-  cached[dev & 31].store(n, std::memory_order_relaxed);
-  return n;
-}
-
-constexpr int kPersistPFU = 16;          // 16-byte loads per thread that carry the next tile (256 threads x 16 x 16 B = 64 KiB)
-
-template <typename T, int MF, int NF>
-inline int launch_pair_persist(const ConvDesc* ds, const PairArgs3& a, int batch, hipStream_t stream, bool* taken) {
-  *taken = false;
-  const ConvDesc& d = ds[0];
-  int halo1 = 0;
-  for (int i = 0; i < a.n; ++i) halo1 = std::max(halo1, (ds[i].taps - 1) * ds[i].dil);
-  const int tile_rows = (NF + 1) * 16 + halo1;
-  const int cpr = d.CinP >> 3;
-  const size_t lds = (size_t)(tile_rows + NF * 16) * d.CinP * 2;
-  const int tiles = ceil_div(a.p[0].T, NF * 16);
-  const long items = (long)tiles * batch * a.n;
-  int cus = device_cu_count();
-  const int mode = pair_persist_mode();
-  if (pair_grid_cap() > 0) cus = std::min(cus, pair_grid_cap());
-  // worth it when every CU gets several tiles (the first one's load is exposed, the others ride under GEMM2)
-  if (cus <= 0 || mode == 0 || (mode == 1 && items < 3L * cus) || lds > 160 * 1024 || (long)tile_rows * cpr > 256L * kPersistPFU) return QVC_OK;
-  *taken = true;
-  const dim3 grid((unsigned)std::min<long>(items, cus));
-  if (d.CinP == 128) {                                     // the shipped stage-2 width: row pitch known at compile time
-    auto kern = rbpair_persist_kernel<T, MF, NF, kPersistPFU, 256>;
-    static std::atomic<uint32_t> lds_ok{0};
-    if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, tiles, batch, tile_rows);
-  } else {
-    auto kern = rbpair_persist_kernel<T, MF, NF, kPersistPFU, 0>;
-    static std::atomic<uint32_t> lds_ok{0};
-    if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(kern))) return QVC_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, tiles, batch, tile_rows);
-  }
-  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
-}
-
-
 template <typename T, typename TS>
 int launch_pair_typed(const ConvDesc* ds, const PairArgs3& a, int batch, void* stream_v, int* nf_out) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const ConvDesc& d = ds[0];
-  if (d.WM == 4 && pair_persist_mode() != 0 && std::is_same<T, TS>::value) {
-    bool taken = false;
-    int st = QVC_OK;
-    if (d.MF == 2) st = launch_pair_persist<T, 2, 10>(ds, a, batch, stream, &taken);
-    else if (d.MF == 1) st = launch_pair_persist<T, 1, 10>(ds, a, batch, stream, &taken);
-    if (taken || st != QVC_OK) { if (nf_out) *nf_out = 110; return st; }
-  }
   switch (d.WM * 10 + d.MF) {
     case 41: return launch_pair_nf<T, 1, 4, 4, TS>(ds, a, batch, stream, nf_out);
     case 42: return launch_pair_nf<T, 2, 4, 4, TS>(ds, a, batch, stream, nf_out);

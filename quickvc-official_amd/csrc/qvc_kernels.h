@@ -1,5 +1,6 @@
 // qvc_kernels.h -- launch-side view of the gfx950 kernels (arguments + launcher prototypes).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include "qvc_plan.h"
 
@@ -143,6 +144,9 @@ struct WnStackArgs {
   float* z = nullptr; int64_t z_bs = 0; int32_t z_ts = 0;
   float post_sign = -1.f;   // -1: reverse flow, x1 - m (modules.py:217); +1: forward flow, m + x1
   Ragged rg;
+#ifdef QVC_STAMP
+  unsigned long long* stamps = nullptr;   // developer build only (tools/conv_bench): [workgroup][16 waves][32] phase stamps
+#endif
 };
 
 struct GemvArgs {
@@ -195,12 +199,29 @@ struct SpkEmbedArgs {   // relu(linear(h)) / ||.||, mean over an utterance's par
   int32_t utterances, n_part, H;
 };
 
-// Developer / test switches of the pair launcher (process-wide, read from the environment on first use):
-//   QVC_PAIR_PERSIST = 0 (default): never use the persistent pair kernel; 1: when every CU gets >= 3 tiles;
-//                      2: whenever the layout supports it (tests: small shapes still exercise it)
-//   QVC_PAIR_GRID    = N: at most N persistent workgroups (tests: makes a workgroup walk several tiles on tiny inputs)
-int& pair_persist_mode();
-int& pair_grid_cap();
+// Developer / test switches.  Process-wide integers that start at their production value and change ONLY through
+// qvc_debug_set() (include/qvc.h): the library never reads the environment, so nothing inherited by a deployment
+// can alter launch shapes or kernel selection.  The GPU tests flip them in-process to prove the variants equal.
+enum DebugSwitch : int32_t {
+  DBG_POST_TAIL = 0,        // 1 (default): conv_post + iSTFT / band synthesis as one launch where post_tail_supported(); 0: two launches
+  DBG_POST_TAIL_NF,         // column fragments per wave of post_tail_kernel: 4 (default, 128-frame tile) or 2
+  DBG_PAIR_WIDE_LAUNCH,     // 1 (default): the three chains of an 8-wave pair layout share a launch; 0: one chain per launch
+  DBG_PAIR_CM4,             // 1 (default): chain-major grid for three-chain launches of 4-wave layouts; 0: chains interleaved (x % n)
+  DBG_CONV_CL,              // 1 (default): chunk-loop variant of the conv kernel where it applies; 0: one workgroup per row chunk
+  DBG_WN_CHUNK,             // 0 (default): 4 WaveNet layers per stack launch; n > 0: n layers; -1: one launch per layer, pre / post as convs
+  DBG_PAIR_CHAIN3,          // 1 (default): the three pairs of a short-kernel ResBlock chain in one launch where supported; 0: off
+  DBG_WN_KERNEL,            // WaveNet stack kernel variant (0 = default)
+  DBG_COUNT
+};
+inline std::atomic<int32_t>* debug_table() {
+  static std::atomic<int32_t> t[DBG_COUNT] = {{1}, {4}, {1}, {1}, {1}, {0}, {1}, {0}};
+  return t;
+}
+inline int debug_get(int which) { return debug_table()[which].load(std::memory_order_relaxed); }
+inline const char* const* debug_names() {
+  static const char* const n[DBG_COUNT] = {"post_tail", "post_tail_nf", "pair_wide_launch", "pair_cm4", "conv_cl", "wn_chunk", "pair_chain3", "wn_kernel"};
+  return n;
+}
 
 // Launchers return a QVC_* status.  `stream` is a hipStream_t.
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out = nullptr);
@@ -209,14 +230,12 @@ int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, i
 int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 bool wn_stack_supported(const ConvDesc& din, int layers);
 int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dtype, void* stream);
+int wn_stack_variant(const ConvDesc& din, const WnStackArgs& a);   // 2: the continuous-stream kernel (qvc_wn2_impl.h), 1: the generic one
 int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 int launch_gemv(const GemvArgs& a, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
 int launch_tail(const TailArgs& a, void* stream);
 int launch_post_tail(const ConvDesc& d, PostTailArgs a, int batch, int dtype, void* stream);
-// Developer / test switch (environment QVC_POST_TAIL, read on first use): 1 (default) fuse conv_post + tail where
-// post_tail_supported(); 0: always two launches
-int& post_tail_mode();
 
 // Instantiation entry (one translation unit per operand dtype).
 template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a, int batch, int epi, void* stream, int* nf_out);

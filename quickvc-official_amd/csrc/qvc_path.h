@@ -36,6 +36,9 @@ struct Path {
   const int32_t* pos = nullptr;
   int32_t off = 0;
   Ragged rg(int mul, int add = 0) const { Ragged r; r.lens = lens; r.pos = pos; r.mul = mul; r.add = add; r.off = off; return r; }
+  // unit frames as they are on disk (dataset/encode.py:38: (frames, 256) per utterance), i.e. [B][T][unit_channels],
+  // instead of the reference's in-memory (B, 256, T) (data_utils_new_new.py:121-122 transposes after loading)
+  bool unit_fm = false;
   // streaming: stage-0 ResBlock outputs handed over from a previous window instead of this call's own (dec_back)
   const void* s0_override[3] = {nullptr, nullptr, nullptr};
 
@@ -126,7 +129,8 @@ struct Path {
     const int H = c.hidden_channels, C = c.inter_channels;
     {
       ConvArgs a = args(P.enc_pre);
-      a.x = unit; a.x_kind = XK_F32_CM; a.x_bs = (int64_t)c.unit_channels * T; a.x_ts = T; a.T_in = T;
+      a.x = unit; a.x_bs = (int64_t)c.unit_channels * T; a.T_in = T;
+      if (unit_fm) { a.x_kind = XK_F32_FM; a.x_ts = c.unit_channels; } else { a.x_kind = XK_F32_CM; a.x_ts = T; }
       a.Nq = T; a.T_out = T; a.rg = rg(1);
       a.y32 = wsp<float>(W.xw); a.y32_bs = (int64_t)T * H; a.y32_ts = H;
       conv(P.enc_pre, a, dtype_wn());
@@ -325,10 +329,8 @@ struct Path {
       // 3 x (19 + 31 + 43) us).
       const bool few_tiles = (int64_t)B * t_out * NB <= 256 * 32;
       const bool wide = block_waves(st.c1[0]) != kWaves;
-      static const int wide_mode = [] { const char* e = getenv("QVC_PAIR_WIDE_LAUNCH"); return e ? atoi(e) : 1; }();   // 0: one chain per launch
-      const int per_launch = (!wide || few_tiles || wide_mode) ? NB : 1;
-      static const int cm4 = [] { const char* e = getenv("QVC_PAIR_CM4"); return e ? atoi(e) : 1; }();   // 0: interleave the chains of 4-wave layouts (x % n)
-      const int chain_major = ((wide || cm4) && !few_tiles) ? 1 : 0;
+      const int per_launch = (!wide || few_tiles || debug_get(DBG_PAIR_WIDE_LAUNCH)) ? NB : 1;   // 0: one chain per launch
+      const int chain_major = ((wide || debug_get(DBG_PAIR_CM4)) && !few_tiles) ? 1 : 0;           // 0: 4-wave layouts interleave the chains (x % n)
       if (fused) {
         for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
           // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the

@@ -212,8 +212,7 @@ template <typename T>
 int launch_post_tail_typed(const ConvDesc& d, const PostTailArgs& a, int batch, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (!post_tail_supported(d) || a.F < 2 || !a.c.x2 || !a.c.x3 || a.c.x_kind != XK_OP_FM) return QVC_ERR_BAD_CONFIG;
-  static const int nf = [] { const char* e = getenv("QVC_POST_TAIL_NF"); return e ? atoi(e) : 4; }();   // developer sweep
-  if (nf == 2) return launch_post_tail_nf<T, 2>(d, a, batch, stream);
+  if (debug_get(DBG_POST_TAIL_NF) == 2) return launch_post_tail_nf<T, 2>(d, a, batch, stream);
   return launch_post_tail_nf<T, 4>(d, a, batch, stream);
 }
 

@@ -22,10 +22,12 @@ namespace qvc {
 // has to stay out of the way.  (Round 1 walked the weight row from global memory, 16 loads at a time: four
 // dependent round trips per workgroup, 16-19 us.)
 constexpr int kGR = 16, kGB = 32, kGS = kGB + 1, kGT = kGR * kGB;
+// the g region doubles as the [kGB][kGR + 1] output transpose buffer: small gin must not let that run into the weights
+__host__ __device__ constexpr int gemv_g_floats(int gin) { return gin * kGS > kGB * (kGR + 1) ? gin * kGS : kGB * (kGR + 1); }
 __global__ __launch_bounds__(kGT) void cond_gemv_kernel(const GemvArgs a) {
-  extern __shared__ float s_gv[];                       // [gin][kGS] g, then [kGR][gin] weights
+  extern __shared__ float s_gv[];                       // [max(gin*kGS, kGB*(kGR+1))] g / output transpose, then [kGR][gin] weights
   float* s_g = s_gv;
-  float* s_w = s_gv + a.gin * kGS;
+  float* s_w = s_gv + gemv_g_floats(a.gin);
   const int tid = threadIdx.x;
   const int r = tid >> 5, bl = tid & 31;
   const int row0 = blockIdx.x * kGR;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(kGT) void cond_gemv_kernel(const GemvArgs a) {
 
 int launch_gemv(const GemvArgs& a, void* stream) {
   if (a.rows <= 0) return QVC_OK;
-  const size_t lds = ((size_t)a.gin * kGS + (size_t)kGR * a.gin) * 4;
+  const size_t lds = ((size_t)gemv_g_floats(a.gin) + (size_t)kGR * a.gin) * 4;
   if (a.gin % 4 || a.gin > 512 || lds > 160 * 1024) return QVC_ERR_BAD_CONFIG;
   static std::atomic<uint32_t> lds_ok{0};                  // > 64 KiB dynamic LDS: opt in once per device
   if (!allow_big_lds(lds_ok, reinterpret_cast<const void*>(cond_gemv_kernel))) return QVC_ERR_LAUNCH;
@@ -257,11 +259,6 @@ int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, vo
   return QVC_ERR_BAD_ARG;
 }
 
-int& post_tail_mode() {
-  static int mode = [] { const char* e = std::getenv("QVC_POST_TAIL"); return e ? std::atoi(e) : 1; }();
-  return mode;
-}
-
 int launch_post_tail(const ConvDesc& d, PostTailArgs a, int batch, int dtype, void* stream) {
   a.c.Cin = d.Cin; a.c.CinP = d.CinP; a.c.taps = d.taps; a.c.dil = d.dil; a.c.left = d.left;
   a.c.KS = d.KS(); a.c.nIt = d.nIt(); a.c.nchunk = d.nchunk; a.c.M = d.M;
@@ -273,7 +270,17 @@ int launch_post_tail(const ConvDesc& d, PostTailArgs a, int batch, int dtype, vo
 
 bool wn_stack_supported(const ConvDesc& din, int layers) { return wn_stack_ok(din, layers); }
 
+// qvc_wn2.hip: the continuous-stream stack kernel for the shipped shape (debug switch "wn_kernel" = 1: always the generic one)
+template <typename T> int launch_wn_stack2_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream);
+bool wn_stack2_supported(const ConvDesc& din, const WnStackArgs& a);
+int wn_stack_variant(const ConvDesc& din, const WnStackArgs& a) { return debug_get(DBG_WN_KERNEL) == 0 && wn_stack2_supported(din, a) ? 2 : 1; }
+
 int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dtype, void* stream) {
+  if (wn_stack_variant(din, a) == 2) {
+    if (dtype == QVC_F16) return launch_wn_stack2_typed<_Float16>(din, a, batch, stream);
+    if (dtype == QVC_BF16) return launch_wn_stack2_typed<__bf16>(din, a, batch, stream);
+    return QVC_ERR_BAD_ARG;
+  }
   if (dtype == QVC_F16) return launch_wn_stack_typed<_Float16>(din, a, batch, stream);
   if (dtype == QVC_BF16) return launch_wn_stack_typed<__bf16>(din, a, batch, stream);
   return QVC_ERR_BAD_ARG;
@@ -283,15 +290,6 @@ int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream,
   if (dtype == QVC_F16) return launch_wn_typed<_Float16>(din, a, batch, stream, nf_out);
   if (dtype == QVC_BF16) return launch_wn_typed<__bf16>(din, a, batch, stream, nf_out);
   return QVC_ERR_BAD_ARG;
-}
-
-int& pair_persist_mode() {
-  static int mode = [] { const char* e = std::getenv("QVC_PAIR_PERSIST"); return e ? std::atoi(e) : 0; }();
-  return mode;
-}
-int& pair_grid_cap() {
-  static int cap = [] { const char* e = std::getenv("QVC_PAIR_GRID"); return e ? std::atoi(e) : 0; }();
-  return cap;
 }
 
 int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype, void* stream, int* nf_out) {

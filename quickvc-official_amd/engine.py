@@ -177,6 +177,15 @@ class QvcEngine:
         L.check(self.lib, st, "qvc_stream_step")
 
     @_on_device
+    def stream_reset_slot(self, state: torch.Tensor, batch: int, hop: int, slot: int, length: int, pos: torch.Tensor,
+                          lens: torch.Tensor) -> None:
+        """qvc_stream_reset_slot: zero slot `slot`'s ring rows, pos[slot] = 0, lens[slot] = length (on the current stream)."""
+        st = self.lib.qvc_stream_reset_slot(ctypes.byref(self.cfg), state.data_ptr(), state.numel(), batch, hop, int(slot),
+                                            int(length), pos.data_ptr(), lens.data_ptr(),
+                                            torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib, st, "qvc_stream_reset_slot")
+
+    @_on_device
     def speaker_embed(self, mel: torch.Tensor) -> torch.Tensor:
         """SpeakerEncoder.embed_utterance for a batch (models.py:528-546): mel (U, n_mel, F) -> g (U, gin)."""
         if mel.dim() != 3 or mel.shape[1] != int(self.cfg.n_mel_channels) or mel.shape[2] < 1:

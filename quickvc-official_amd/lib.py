@@ -59,6 +59,10 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_status_string.restype = ctypes.c_char_p
         lib.qvc_status_string.argtypes = [ctypes.c_int]
         lib.qvc_device_check.restype = ctypes.c_int
+        lib.qvc_debug_set.restype = ctypes.c_int
+        lib.qvc_debug_set.argtypes = [ctypes.c_char_p, I]
+        lib.qvc_debug_get.restype = ctypes.c_int
+        lib.qvc_debug_get.argtypes = [ctypes.c_char_p, P(I)]
         lib.qvc_blob_bytes.restype = L
         lib.qvc_blob_bytes.argtypes = [cfgp]
         lib.qvc_pack_weights.restype = ctypes.c_int
@@ -69,6 +73,8 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_infer_batch.argtypes = [cfgp, V, V, V, V, V, I, I, V, L, V]
         lib.qvc_infer_batch_ragged.restype = ctypes.c_int
         lib.qvc_infer_batch_ragged.argtypes = [cfgp, V, V, V, V, V, I, I, V, V, L, V]
+        lib.qvc_infer_batch_ragged_fm.restype = ctypes.c_int
+        lib.qvc_infer_batch_ragged_fm.argtypes = [cfgp, V, V, V, V, V, I, I, V, V, L, V]
         lib.qvc_stream_state_bytes.restype = L
         lib.qvc_stream_state_bytes.argtypes = [cfgp, I, I]
         lib.qvc_stream_workspace_bytes.restype = L
@@ -79,6 +85,8 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_stream_noise_lag_frames.argtypes = [cfgp]
         lib.qvc_stream_step.restype = ctypes.c_int
         lib.qvc_stream_step.argtypes = [cfgp, V, V, L, V, V, V, V, I, I, V, V, V, L, V]
+        lib.qvc_stream_reset_slot.restype = ctypes.c_int
+        lib.qvc_stream_reset_slot.argtypes = [cfgp, V, L, I, I, I, I, V, V, V]
         lib.qvc_aux_create.restype = ctypes.c_int
         lib.qvc_aux_create.argtypes = [P(V)]
         lib.qvc_aux_destroy.restype = ctypes.c_int
@@ -141,10 +149,24 @@ def load_library() -> ctypes.CDLL:
                            "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback")
         lib = ctypes.CDLL(_LIB_PATH)
         declare(lib)
-        if lib.qvc_abi_version() != 7:
+        if lib.qvc_abi_version() != 8:
             raise QvcError("libqvc_hip.so ABI version mismatch")
         _lib = lib
     return _lib
+
+
+def debug_set(name: str, value: int) -> None:
+    """Developer / test switch of the library (include/qvc.h: qvc_debug_set).  The library itself never reads the
+    environment; the GPU tests flip launch-shape variants through this call, in-process."""
+    lib = load_library()
+    check(lib, lib.qvc_debug_set(name.encode(), int(value)), f"qvc_debug_set({name})")
+
+
+def debug_get(name: str) -> int:
+    lib = load_library()
+    v = ctypes.c_int32(0)
+    check(lib, lib.qvc_debug_get(name.encode(), ctypes.byref(v)), f"qvc_debug_get({name})")
+    return int(v.value)
 
 
 def check(lib, status: int, what: str) -> None:

@@ -8,9 +8,9 @@ shapes (so ``utils.load_checkpoint`` of the reference's ``.pth`` works unchanged
 What is different underneath: the sub-modules below are *parameter holders* only.
 There is no PyTorch forward for enc_p / flow / dec: ``infer`` and ``infer_batch``
 hand the raw tensors to ``libqvc_hip.so`` (engine.py), which runs the whole path as
-hand-written gfx950 kernels.  Only the speaker encoder (3-layer LSTM, outside the
-hot path -- SURVEY.md section 8f) runs as PyTorch-ROCm code.  If the HIP library is missing
-or no GPU is present, ``infer`` raises; there is no CPU fallback.
+hand-written gfx950 kernels -- the speaker encoder (3-layer LSTM)
+included.  If the HIP library is missing or no GPU is present, ``infer`` raises; there is
+no CPU fallback and no torch forward anywhere in this module.
 """
 from __future__ import annotations
 
@@ -179,42 +179,37 @@ class GeneratorParams(nn.Module):
 
 
 # ----------------------------------------------------------------------------- speaker encoder
-class SpeakerEncoder(nn.Module):
-    """models.py:507-546 as a torch module: holds the enc_spk.* parameters under the reference's names and is
-    the fp32 torch reference of the HIP speaker-encoder kernels (``SynthesizerTrn.speaker_embed`` is what
-    ``infer`` calls).
+class _LSTMParams(nn.Module):
+    """Parameters of ``nn.LSTM(input, hidden, layers)`` under PyTorch's own names (weight_ih_l{k}, weight_hh_l{k},
+    bias_ih_l{k}, bias_hh_l{k}; gate order i, f, g, o) -- what the reference's checkpoint stores for ``enc_spk.lstm``."""
 
-    ``embed_utterance`` keeps the reference semantics: 128-frame partials at hop 64
-    plus the last 128 frames, mean of the L2-normalised partial embeddings, *no*
-    re-normalisation of the mean (models.py:539-541).  Batched here: all partials
-    go through the LSTM in one call.
-    """
+    def __init__(self, input_size: int, hidden: int, layers: int):
+        super().__init__()
+        for k in range(layers):
+            cin = input_size if k == 0 else hidden
+            setattr(self, f"weight_ih_l{k}", nn.Parameter(torch.zeros(4 * hidden, cin)))
+            setattr(self, f"weight_hh_l{k}", nn.Parameter(torch.zeros(4 * hidden, hidden)))
+            setattr(self, f"bias_ih_l{k}", nn.Parameter(torch.zeros(4 * hidden)))
+            setattr(self, f"bias_hh_l{k}", nn.Parameter(torch.zeros(4 * hidden)))
+
+
+class _LinearParams(nn.Module):
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class SpeakerEncoder(nn.Module):
+    """Parameter holder for ``enc_spk.*`` (models.py:507-513: 3-layer LSTM 80 -> hidden, Linear hidden -> embedding).
+
+    No forward: ``SynthesizerTrn.speaker_embed`` runs ``embed_utterance`` (models.py:528-546) on the HIP kernels of
+    csrc/qvc_spk.hip; the fp32 torch restatement used to check them lives in ``oracle/qvc_oracle.py``."""
 
     def __init__(self, mel_n_channels=80, model_num_layers=3, model_hidden_size=256, model_embedding_size=256):
         super().__init__()
-        self.lstm = nn.LSTM(mel_n_channels, model_hidden_size, model_num_layers, batch_first=True)
-        self.linear = nn.Linear(model_hidden_size, model_embedding_size)
-        self.relu = nn.ReLU()
-
-    def forward(self, mels: Tensor) -> Tensor:
-        self.lstm.flatten_parameters()
-        _, (hidden, _) = self.lstm(mels)
-        raw = self.relu(self.linear(hidden[-1]))
-        return raw / torch.norm(raw, dim=1, keepdim=True)
-
-    @torch.no_grad()
-    def embed_utterance(self, mel: Tensor, partial_frames: int = 128, partial_hop: int = 64) -> Tensor:
-        """mel :: (1, frames, n_mel) -> (1, emb)."""
-        if mel.dim() != 3 or mel.size(0) != 1:
-            # the reference raises from inside nn.LSTM for B > 1 (SURVEY 0.5); say why instead
-            raise ValueError(f"embed_utterance expects one utterance (1, frames, n_mel), got {tuple(mel.shape)}")
-        frames = mel.size(1)
-        last = mel[:, -partial_frames:]
-        if frames <= partial_frames:
-            return self(last)
-        starts = range(0, frames - partial_frames, partial_hop)
-        parts = [mel[0, s:s + partial_frames] for s in starts] + [last[0]]
-        return self(torch.stack(parts, 0)).mean(dim=0, keepdim=True)
+        self.lstm = _LSTMParams(mel_n_channels, model_hidden_size, model_num_layers)
+        self.linear = _LinearParams(model_hidden_size, model_embedding_size)
 
 
 # ----------------------------------------------------------------------------- the model
@@ -316,14 +311,10 @@ class SynthesizerTrn(nn.Module):
     def speaker_embed(self, mel: Tensor) -> Tensor:
         """SpeakerEncoder.embed_utterance (models.py:528-546) for a batch: mel (U, 80, F') -> g (U, gin).
 
-        Runs the persistent-LSTM HIP kernels (csrc/qvc_spk.hip).  Speaker widths the kernel does not cover
-        (gin > 256 or gin % 8 != 0) go through ``enc_spk`` -- torch.nn.LSTM on the same GPU -- one utterance
-        at a time, as the reference does.
+        Runs the persistent-LSTM HIP kernels (csrc/qvc_spk.hip).  Speaker widths the kernels do not cover
+        (gin > 256 or gin % 8 != 0) raise ``QvcError`` (QVC_ERR_BAD_CONFIG from the library): there is no torch path.
         """
-        gin = self.model_config["gin_channels"]
-        if gin <= 256 and gin % 8 == 0:
-            return self.engine().speaker_embed(mel)
-        return torch.cat([self.enc_spk.embed_utterance(m[None].transpose(1, 2)) for m in mel], 0)
+        return self.engine().speaker_embed(mel)
 
     @torch.no_grad()
     def infer_batch(self, unit: Tensor, g: Tensor, noise: Optional[Tensor] = None) -> Tensor:

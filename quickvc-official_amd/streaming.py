@@ -117,6 +117,8 @@ class StreamConverter:
         self._len = torch.full((S,), 2 ** 30, dtype=torch.int32, device=dev)
         self._stream = torch.cuda.Stream(dev)
         self._graph = None
+        self._pos_host = [0] * S
+        self._len_host = [2 ** 30] * S
         self.reset()
         if use_graph:
             with torch.cuda.stream(self._stream):
@@ -131,8 +133,18 @@ class StreamConverter:
         self.engine.stream_step(self._state, self._ws, self._unit, self._g, self._noise, self._out, self._pos, self._len)
         self._pos.add_(self.hop)                                 # inside the graph: the position advances with every replay
 
+    def _after_caller(self, *tensors) -> None:
+        """Order the side stream after the caller's current stream (inputs such as a freshly computed ``g`` may still be
+        pending there) and keep device inputs alive until the side stream is done with them."""
+        dev = self.engine.device
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self._stream)
+
     def reset(self, g: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None) -> None:
-        """Start new streams: zero state, position 0; ``g`` (S, gin) speaker embeddings; ``lengths`` (S,) if known."""
+        """Start new streams in ALL slots: zero state, position 0; ``g`` (S, gin) speaker embeddings; ``lengths`` (S,) if known."""
+        self._after_caller(g, lengths)
         with torch.cuda.stream(self._stream):
             self._state.zero_()
             self._pos.zero_()
@@ -142,11 +154,44 @@ class StreamConverter:
             if lengths is not None:
                 self._len.copy_(torch.as_tensor(lengths, dtype=torch.int32))
         self._stream.synchronize()
+        self._pos_host = [0] * self.streams
+        self._len_host = [2 ** 30] * self.streams if lengths is None else [int(v) for v in torch.as_tensor(lengths).tolist()]
 
     def end(self, lengths) -> None:
-        """Tell the converter where the streams end (frames); keep stepping until ``position - lag >= length`` to flush."""
+        """Tell the converter where ALL streams end (frames); keep stepping until ``position - lag >= length`` to flush."""
+        self._after_caller(lengths)
         with torch.cuda.stream(self._stream):
             self._len.copy_(torch.as_tensor(lengths, dtype=torch.int32))
+        self._len_host = [int(v) for v in torch.as_tensor(lengths).tolist()]
+
+    # ---- per-slot lifecycle: streams of a server start and end at different times
+    def start(self, slot: int, g: torch.Tensor, length: Optional[int] = None) -> None:
+        """Admit a new stream into ``slot``: that slot's ring rows are zeroed and its position goes back to 0 on the
+        device (qvc_stream_reset_slot); the other slots keep running and the captured graph is unchanged.  ``g`` (gin,)
+        or (1, gin): the stream's speaker embedding; ``length``: its frame count if already known."""
+        if not 0 <= slot < self.streams:
+            raise ValueError(f"slot {slot} outside [0, {self.streams})")
+        n = 2 ** 30 if length is None else int(length)
+        self._after_caller(g)
+        with torch.cuda.stream(self._stream):
+            self.engine.stream_reset_slot(self._state, self.streams, self.hop, slot, n, self._pos, self._len)
+            self._g[slot].copy_(g.reshape(-1), non_blocking=True)
+        self._pos_host[slot] = 0
+        self._len_host[slot] = n
+
+    def end_slot(self, slot: int, length: int) -> None:
+        """The stream in ``slot`` ends after ``length`` frames; it is flushed once ``finished(slot)``."""
+        with torch.cuda.stream(self._stream):
+            self._len[slot:slot + 1].fill_(int(length))
+        self._len_host[slot] = int(length)
+
+    def position(self, slot: int) -> int:
+        """First frame the NEXT step feeds into ``slot`` (host mirror of the device counter)."""
+        return self._pos_host[slot]
+
+    def finished(self, slot: int) -> bool:
+        """Every output frame of the stream in ``slot`` has been produced: the slot can take a new stream."""
+        return self._pos_host[slot] - self.lag >= self._len_host[slot]
 
     @torch.no_grad()
     def step(self, unit_new: torch.Tensor, noise_new: torch.Tensor) -> torch.Tensor:
@@ -164,6 +209,7 @@ class StreamConverter:
                 self._one_step()
             out = self._out.clone()
         torch.cuda.current_stream(dev).wait_stream(self._stream)
+        self._pos_host = [p + self.hop for p in self._pos_host]
         return out
 
     @torch.no_grad()

@@ -4,10 +4,14 @@ against the CPU oracle and against the golden vectors recorded from the referenc
 Tolerances (floating point, stated here as the task requires):
   * one conv through the MFMA kernel vs the same conv in fp64 on operands rounded to the MFMA
     operand type: max abs error <= 2e-5 * (1 + |y|max)  (fp32 accumulation order only);
-  * whole path, f16 operands: waveform SNR >= 45 dB per utterance (target of BASELINE.json: 40 dB;
-    measured ~52.6 dB); bf16 operands: >= 30 dB (measured ~34.5 dB -- documented as NOT meeting
-    the 40 dB bar, which is why f16 is the default operand type);
-  * fp32 tail (iSTFT + synthesis FIR): SNR >= 100 dB.
+  * whole path, waveform SNR per utterance against the fp32 oracle / the reference's goldens
+    (BASELINE.json's bar: 40 dB): f16 operands >= 45 dB (measured 52-53 dB); the mixed mode bf16x
+    (bf16 MFMA operands in the fused ResBlock pairs, f16 residual stream, f16 elsewhere -- the mode
+    bench.py runs) >= 40 dB on every configuration tested (shipped config 45.6 dB); all-bf16 >= 30 dB
+    (measured 34 dB: documented as NOT meeting the bar, DESIGN.md section 2);
+  * fp32 tail (iSTFT + synthesis FIR): SNR >= 100 dB;
+  * launch-shape / kernel-selection variants (library debug switches, flipped in-process through
+    qvc_debug_set): bit-identical, or >= 100 dB where the K order differs.
 """
 import ctypes
 
@@ -34,6 +38,21 @@ def lib():
     l = L.load_library()                       # raises if the HIP library is missing: no fallback
     assert l.qvc_device_check() == 0
     return l
+
+
+DEBUG_DEFAULTS = {"post_tail": 1, "post_tail_nf": 4, "pair_wide_launch": 1, "pair_cm4": 1, "conv_cl": 1, "wn_chunk": 0,
+                  "pair_chain3": 1, "wn_kernel": 0}
+
+
+@pytest.fixture(autouse=True)
+def _debug_switches_at_defaults():
+    """Every test starts and ends with the library's developer switches at their production values."""
+    from quickvc_official_amd import lib as L
+    for k, v in DEBUG_DEFAULTS.items():
+        L.debug_set(k, v)
+    yield
+    for k, v in DEBUG_DEFAULTS.items():
+        L.debug_set(k, v)
 
 
 def _engine(entry, sd, dev, dtype):
@@ -201,8 +220,8 @@ def test_wn_stack_entry_point(lib, dev):
         eng.wn_stack(1, _fm(x), None)                                  # a coupling stack needs g
 
 
-def test_per_layer_wn_kernel_with_big_lds_tiles(lib, dev, monkeypatch):
-    """hidden = 256 on the per-layer WaveNet kernel (QVC_WN_CHUNK=-1) with >= 512 tiles: 64-frame tiles need
+def test_per_layer_wn_kernel_with_big_lds_tiles(lib, dev):
+    """hidden = 256 on the per-layer WaveNet kernel (debug switch wn_chunk = -1) with >= 512 tiles: 64-frame tiles need
     (64 + 4 + 64) * 512 B = 67.6 KB of dynamic LDS, i.e. the > 64 KiB opt-in (it used to be missing there)."""
     import quickvc_official_amd as q
     from quickvc_official_amd.engine import QvcEngine
@@ -213,8 +232,9 @@ def test_per_layer_wn_kernel_with_big_lds_tiles(lib, dev, monkeypatch):
     B, T = 16, 1024                                                    # 16 * ceil(1024 / 32) = 512 tiles
     unit, _g, noise = make_synthetic_inputs(B, T, 256, 64, 32, seed0=9)
     eng = QvcEngine(model.model_config, sd, dev)
+    from quickvc_official_amd import lib as L
     z_stack = eng.enc_p(unit, noise)
-    monkeypatch.setenv("QVC_WN_CHUNK", "-1")
+    L.debug_set("wn_chunk", -1)
     z_layer = eng.enc_p(unit, noise)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(z_layer).all())
@@ -225,76 +245,75 @@ def test_per_layer_wn_kernel_with_big_lds_tiles(lib, dev, monkeypatch):
     assert snr_db(_fm(want), z_layer[:1].cpu()) >= 45.0
 
 
-def test_persistent_pair_kernel_matches(lib, dev):
-    """The opt-in persistent ResBlock-pair kernel (QVC_PAIR_PERSIST=2; one workgroup per CU walks the tile list,
-    next tile prefetched under GEMM2, residual from LDS) gives bit-identical results to the default
-    one-tile-per-workgroup kernel: same K order, same roundings.  QVC_PAIR_GRID caps the grid so that every
-    workgroup really walks several tiles of several chains on this small input."""
-    import subprocess, sys, os, tempfile
-    from helpers import ROOT
-    code = (
-        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); sys.path.insert(0, %r + '/oracle');\n"
-        "from helpers import load_case, regenerate\n"
-        "import quickvc_official_amd as q\n"
-        "from quickvc_official_amd.engine import QvcEngine\n"
-        "entry, _ = load_case('full_b2'); m, sd, unit, g, noise = regenerate(entry)\n"
-        "eng = QvcEngine(dict(q.SynthesizerTrn(641, 32, **entry['config']).model_config), sd, torch.device('cuda:0'))\n"
-        "out, recs = eng.infer_batch_timed(unit.cuda(), g.cuda(), noise.cuda()); torch.cuda.synchronize()\n"
-        "print('NAMES', sorted(set(r['name'] for r in recs if r['name'].startswith('rbpair'))))\n"
-        "torch.save(out.cpu(), sys.argv[1])\n") % (ROOT, ROOT, ROOT)
-    outs = []
-    with tempfile.TemporaryDirectory() as td:
-        for mode, grid in (("0", "0"), ("2", "7")):
-            path = os.path.join(td, f"o{mode}.pt")
-            env = dict(os.environ, QVC_PAIR_PERSIST=mode, QVC_PAIR_GRID=grid)
-            res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
-            assert res.returncode == 0, res.stderr[-2000:]
-            assert ("rbpair_persist<" in res.stdout) == (mode == "2"), res.stdout
-            outs.append(torch.load(path))
-    assert torch.equal(outs[0], outs[1])
-
-
 def test_fused_post_tail_matches_two_launches(lib, dev):
-    """conv_post + iSTFT/FIR tail as one launch (the default, qvc_post_tail_impl.h) against QVC_POST_TAIL=0 (conv_post
-    -> fp32 frames in memory -> istft_synth_kernel): same K order in the GEMM, same per-item math in the tail, so the
-    waveforms must agree bit for bit -- whole batch (two utterances, 250 frames: tiles at both ends and in the
-    middle) and a ragged batch (tiles past an utterance's end)."""
-    import subprocess, sys, os, tempfile
-    from helpers import ROOT
-    code = (
-        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); sys.path.insert(0, %r + '/oracle');\n"
-        "from helpers import load_case, regenerate\n"
-        "import quickvc_official_amd as q\n"
-        "from quickvc_official_amd.engine import QvcEngine\n"
-        "entry, _ = load_case('full_b2'); m, sd, unit, g, noise = regenerate(entry)\n"
-        "res = {}\n"
-        "for dt in ('f16', 'bf16x'):\n"
-        "    eng = QvcEngine(dict(q.SynthesizerTrn(641, 32, **entry['config']).model_config, operand_dtype=dt), sd, torch.device('cuda:0'))\n"
-        "    out, recs = eng.infer_batch_timed(unit.cuda(), g.cuda(), noise.cuda()); torch.cuda.synchronize()\n"
-        "    print('NAMES', dt, sorted(set(r['name'] for r in recs if r['name'].startswith(('post_tail', 'istft')))))\n"
-        "    lens = torch.tensor([unit.shape[2], 77], dtype=torch.int32)\n"
-        "    rag = eng.infer_batch_ragged(unit.cuda(), g.cuda(), noise.cuda(), lens.cuda()); torch.cuda.synchronize()\n"
-        "    res[dt] = (out.cpu(), rag.cpu())\n"
-        "torch.save(res, sys.argv[1])\n") % (ROOT, ROOT, ROOT)
+    """conv_post + iSTFT/FIR tail as one launch (the default, qvc_post_tail_impl.h) against the debug switch
+    post_tail = 0 (conv_post -> fp32 frames in memory -> istft_synth_kernel): same K order in the GEMM, same per-item
+    math in the tail, so the waveforms must agree bit for bit -- whole batch (two utterances, 250 frames: tiles at both
+    ends and in the middle) and a ragged batch (tiles past an utterance's end).  Third variant: the launch shapes of
+    earlier rounds -- chains interleaved on the CUs, one chain per launch at stage 1, one workgroup per row chunk in
+    up-sampler 1, no k = 3 chain fusion: where a workgroup runs must not change a bit."""
+    from quickvc_official_amd import lib as L
+    entry, _ = load_case("full_b2")
+    _m, sd, unit, g, noise = regenerate(entry)
+    variants = ({"post_tail": 1}, {"post_tail": 0},
+                {"post_tail": 1, "pair_cm4": 0, "pair_wide_launch": 0, "conv_cl": 0, "pair_chain3": 0})
     outs = []
-    # third run: the launch shapes of earlier rounds -- chains interleaved on the CUs, one chain per launch at stage 1,
-    # one workgroup per row chunk in up-sampler 1: where a workgroup runs must not change a bit
-    variants = ({"QVC_POST_TAIL": "1"}, {"QVC_POST_TAIL": "0"},
-                {"QVC_POST_TAIL": "1", "QVC_PAIR_CM4": "0", "QVC_PAIR_WIDE_LAUNCH": "0", "QVC_CONV_CL": "0"})
-    with tempfile.TemporaryDirectory() as td:
-        for i, extra in enumerate(variants):
-            path = os.path.join(td, f"o{i}.pt")
-            res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), capture_output=True,
-                                 text=True, timeout=600)
-            assert res.returncode == 0, res.stderr[-2000:]
-            fusedtail = extra["QVC_POST_TAIL"] == "1"
-            assert ("post_tail<" in res.stdout) == fusedtail and ("istft_synth" in res.stdout) == (not fusedtail), res.stdout
-            outs.append(torch.load(path))
+    for extra in variants:
+        for k, v in DEBUG_DEFAULTS.items():
+            L.debug_set(k, extra.get(k, v))
+        res = {}
+        for dt in ("f16", "bf16x"):
+            eng = _engine(entry, sd, dev, dt)
+            out, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
+            torch.cuda.synchronize()
+            names = sorted(set(r["name"] for r in recs if r["name"].startswith(("post_tail", "istft"))))
+            fusedtail = extra["post_tail"] == 1
+            assert any(n.startswith("post_tail<") for n in names) == fusedtail, names
+            assert any(n.startswith("istft_synth") for n in names) == (not fusedtail), names
+            lens = torch.tensor([unit.shape[2], 77], dtype=torch.int32)
+            rag = eng.infer_batch_ragged(unit.to(dev), g.to(dev), noise.to(dev), lens.to(dev))
+            torch.cuda.synchronize()
+            res[dt] = (out.cpu(), rag.cpu())
+        outs.append(res)
     for dt in ("f16", "bf16x"):
         for other in (1, 2):
             assert torch.equal(outs[0][dt][0], outs[other][dt][0]), (dt, other)
             assert torch.equal(outs[0][dt][1], outs[other][dt][1]), (dt, other)
         assert outs[0][dt][1][1, 0, 320 * 77:].abs().max() == 0 and outs[0][dt][1][1, 0, :320 * 77].abs().max() > 0
+
+
+def test_continuous_stream_wn_kernel_is_bit_identical(lib, dev):
+    """The continuous-stream WaveNet stack kernel (qvc_wn2_impl.h: the default at hidden 192 / kernel 5) against the
+    generic stack kernel (debug switch wn_kernel = 1): same K order per output, same roundings -> bit-identical, for
+    enc_p (4 chained launches, the last with the network's final layer), the coupling layers (pre / post fused),
+    a ragged batch and a single short utterance."""
+    from quickvc_official_amd import lib as L
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    unit, g, noise = make_synthetic_inputs(5, 250, 256, 192, 256, seed0=4100)
+    lens = torch.tensor([250, 33, 181, 64, 2], dtype=torch.int32)
+    res = []
+    for variant in (0, 1):
+        L.debug_set("wn_kernel", variant)
+        per = {}
+        for dt in ("f16", "bf16"):
+            eng = _engine(entry, sd, dev, dt)
+            z = eng.enc_p(unit, noise)
+            zf = eng.flow_reverse(z, g)
+            ws = [eng.wn_stack(i, z.new_zeros(5, 250, 192).normal_(generator=torch.Generator(device=dev).manual_seed(7 + i)), g) for i in range(5)]
+            out, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
+            rag = eng.infer_batch_ragged(unit.to(dev), g.to(dev), noise.to(dev), lens.to(dev))
+            one = eng.infer_batch(unit[:1, :, :40].to(dev), g[:1].to(dev), noise[:1, :, :40].to(dev))
+            torch.cuda.synchronize()
+            n2 = sum(r["name"].startswith("wn_stack2<") for r in recs)
+            n1 = sum(r["name"].startswith("wn_stack<") for r in recs)
+            assert (n2, n1) == ((8, 0) if variant == 0 else (0, 8)), (variant, n2, n1)
+            per[dt] = [t.cpu() for t in (z, zf, out, rag, one, *ws)]
+        res.append(per)
+    for dt in ("f16", "bf16"):
+        for x, y in zip(res[0][dt], res[1][dt]):
+            assert torch.equal(x, y), dt
 
 
 def test_mixed_bf16x_mode_meets_40_db(lib, dev):
@@ -371,10 +390,11 @@ def test_infer_api_matches_reference_semantics(lib, dev):
     assert snr_db(2.0 * spk["infer_o"], o2.cpu().numpy()) >= 45.0
 
 
-def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev, monkeypatch):
-    """The whole-stack WaveNet kernel (4 layers per launch, overlap-tiled, coupling pre/post fused) against the
-    path for configurations it does not cover -- one fused launch per layer, pre / post as separate convs --
-    selected with QVC_WN_CHUNK=-1.  Same K order per frame -> identical results."""
+def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev):
+    """The whole-stack WaveNet kernels (4 layers per launch, overlap-tiled, coupling pre/post fused) against the
+    path for configurations they do not cover -- one fused launch per layer, pre / post as separate convs --
+    selected with the debug switch wn_chunk = -1.  Same K order per frame -> identical results."""
+    from quickvc_official_amd import lib as L
     from quickvc_official_amd.synth import make_synthetic_inputs
     entry, _ = load_case("full_b1")
     _m, sd, _u, _g, _n = regenerate(entry)
@@ -383,14 +403,14 @@ def test_wn_stack_kernel_equals_per_layer_kernels(lib, dev, monkeypatch):
     z_stack = eng.enc_p(unit, noise)
     zf_stack = eng.flow_reverse(z_stack, g)
     _, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
-    assert sum(r["name"].startswith("wn_stack<f16,W12,L4") for r in recs) == 8      # enc_p: 4 launches of 4 layers; 4 flows
-    monkeypatch.setenv("QVC_WN_CHUNK", "-1")
+    assert sum(r["name"].startswith("wn_stack2<f16,W12,L4") for r in recs) == 8      # enc_p: 4 launches of 4 layers; 4 flows
+    L.debug_set("wn_chunk", -1)
     z_layer = eng.enc_p(unit, noise)
     zf_layer = eng.flow_reverse(z_stack, g)
     _, recs = eng.infer_batch_timed(unit.to(dev), g.to(dev), noise.to(dev))
     torch.cuda.synchronize()
     names = [r["name"] for r in recs]
-    assert sum(n.startswith("wn_layer<f16,W12") for n in names) == 32 and not any(n.startswith("wn_stack<") for n in names)
+    assert sum(n.startswith("wn_layer<f16,W12") for n in names) == 32 and not any(n.startswith("wn_stack") for n in names)
     assert sum(n.startswith("conv<") for n in names) == 2 + 4 * 2 + 1 + 2          # + 4 x (pre, post); conv_post rides in post_tail
     assert snr_db(z_layer.cpu(), z_stack.cpu()) >= 100.0
     assert snr_db(zf_layer.cpu(), zf_stack.cpu()) >= 100.0
@@ -847,9 +867,10 @@ def test_convert_cli_on_the_shape_of_the_reference_demo_pair(lib, dev, tmp_path)
 
 def test_convert_cli_two_ranks_rehearsal(lib, dev, tmp_path):
     """BASELINE configs[3] control flow on a one-GPU box: the CLI started as TWO ranks (RANK / WORLD_SIZE as
-    torch.distributed.run sets them, QVC_CLI_REHEARSAL=1 puts both on cuda:0).  Each rank plans from the .npy
-    headers, converts only its own shard through the ragged path and writes its own files: together exactly one
-    wav per list line, each 320 samples per unit frame.  (There is no collective in this mode.)"""
+    torch.distributed.run sets them; ``--device 0`` puts both on cuda:0).  Each rank plans from the .npy headers,
+    converts only its own shard through the ragged path and writes its own files: together exactly one wav per list
+    line, each 320 samples per unit frame.  There is no collective in this mode, so the ranks run one after the other
+    (nothing in the property under test needs them to share the GPU at the same time)."""
     import json
     import os
     import subprocess
@@ -874,16 +895,13 @@ def test_convert_cli_two_ranks_rehearsal(lib, dev, tmp_path):
         np.save(str(tmp_path / f"{name}.npy"), rng.randn(n, 256).astype(np.float32))
     (tmp_path / "convert.txt").write_text("".join(f"t_{n}|{tmp_path}/{n}.npy|{tmp_path}/spk{i % 2}.wav\n" for i, n in enumerate(frames)))
     outs = [tmp_path / "out0", tmp_path / "out1"]
-    procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", QVC_CLI_REHEARSAL="1", PYTHONPATH=ROOT)
-        procs.append(subprocess.Popen([sys.executable, "-m", "quickvc_official_amd.convert", "--hpfile", str(tmp_path / "config.json"),
-                                       "--ptfile", str(tmp_path / "G_1.pth"), "--txtpath", str(tmp_path / "convert.txt"),
-                                       "--outdir", str(outs[r]), "--seed", "3", "--batch", "2"], env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    for p in procs:
-        so, se = p.communicate(timeout=600)
-        assert p.returncode == 0, se[-3000:]
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", PYTHONPATH=ROOT)
+        res = subprocess.run([sys.executable, "-m", "quickvc_official_amd.convert", "--hpfile", str(tmp_path / "config.json"),
+                              "--ptfile", str(tmp_path / "G_1.pth"), "--txtpath", str(tmp_path / "convert.txt"),
+                              "--outdir", str(outs[r]), "--seed", "3", "--batch", "2", "--device", "0"], env=env, cwd=ROOT,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
     written = [sorted(os.listdir(o)) for o in outs]
     assert sorted(written[0] + written[1]) == sorted(f"t_{n}.wav" for n in frames)       # a partition of the list
     assert written[0] and written[1]
@@ -961,7 +979,7 @@ def test_forward_flow_inverts_reverse_flow_at_benchmark_size(lib, dev):
     directions compute m from the untouched half with the same kernels, so one coupling layer inverts to one fp32
     add + subtract per element; across the four layers that 1e-7 perturbation of the next layer's input now and
     then flips an f16 operand rounding, which bounds the round trip at ~70 dB (asserted >= 60).  The fallback path
-    (QVC_WN_CHUNK=-1: unfused pre/post) must agree with the fused one."""
+    (debug switch wn_chunk = -1: unfused pre/post) must agree with the fused one."""
     from quickvc_official_amd.synth import make_synthetic_inputs
     entry, _ = load_case("full_b1")
     _m, sd, _u, _g, _n = regenerate(entry)
@@ -973,11 +991,8 @@ def test_forward_flow_inverts_reverse_flow_at_benchmark_size(lib, dev):
     torch.cuda.synchronize()
     assert snr_db(z.cpu(), z_p.cpu()) < 40.0                          # the flow did something
     assert snr_db(z.cpu(), back.cpu()) >= 60.0
-    import os
-    os.environ["QVC_WN_CHUNK"] = "-1"
-    try:
-        z_p2 = eng.flow_forward(z[:3], g[:3])
-    finally:
-        del os.environ["QVC_WN_CHUNK"]
+    from quickvc_official_amd import lib as L
+    L.debug_set("wn_chunk", -1)
+    z_p2 = eng.flow_forward(z[:3], g[:3])
     torch.cuda.synchronize()
     assert snr_db(z_p[:3].cpu(), z_p2.cpu()) >= 100.0

