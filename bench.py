@@ -8,7 +8,7 @@ batch, no per-step collective -- the only collective is one weight broadcast at 
 One "step" = one pass of the whole hot path (enc_p -> reverse flow -> generator -> iSTFT +
 band synthesis) over one batch of 32 synthetic utterances already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N worker processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task description) including
@@ -46,6 +46,33 @@ def kernel_source_sha1() -> str:
     return h.hexdigest()
 
 
+def launch_workers(n: int, argv, rehearsal: bool) -> int:
+    """--gpus N without a launcher: start N fresh worker processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would set them) BEFORE this process touches the GPU, forward rank 0's JSON line,
+    and fail if any worker fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: worker(s) failed (rank, exit code): {bad}", file=sys.stderr)
+        return next(c for _, c in bad) or 1
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,8 +84,13 @@ def main() -> None:
                          "streams, f16 elsewhere: BASELINE.json names bf16 and >= 40 dB; all-bf16 measures 34 dB, bf16x 45.6 dB, f16 52 dB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches")
+    ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches (only stages whose pairs do NOT run fused take that path)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="developer switch for a 1-GPU box: every rank on cuda:0 with gloo, to exercise the multi-rank control flow")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args.gpus, sys.argv[1:], args.rehearsal))
 
     import torch
     import torch.distributed as dist
@@ -73,9 +105,7 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the hot path has no CPU fallback)")
-    # Rehearsal switch for a 1-GPU box (never set by the driver): QVC_BENCH_REHEARSAL=1 puts every rank on
-    # cuda:0 and uses gloo, to exercise the multi-rank control flow without a second GPU.
-    rehearsal = os.environ.get("QVC_BENCH_REHEARSAL") == "1"
+    rehearsal = args.rehearsal
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -88,9 +118,9 @@ def main() -> None:
 
     cfg = dict(q.DEFAULT_MODEL_CONFIG)
     model = q.SynthesizerTrn(641, 32, **cfg, operand_dtype=args.dtype)
-    # rank 0 owns the checkpoint; everybody else receives the packed blob in ONE broadcast
-    sd = make_synthetic_state_dict(model, 1234)
-    engine = QvcEngine(model.model_config, sd, device, parallel_branches=args.branches)   # every rank packs; then overwritten:
+    # rank 0 owns the checkpoint and packs it; everybody else allocates an empty blob and receives it in ONE broadcast
+    sd = make_synthetic_state_dict(model, 1234) if rank == 0 else None
+    engine = QvcEngine(model.model_config, sd, device, parallel_branches=args.branches, pack=rank == 0)
     if world > 1:
         qd.broadcast_blob(engine.blob, src=0)                 # RCCL over xGMI, once
     B = args.batch
@@ -160,7 +190,7 @@ def main() -> None:
                    "batch_per_gpu": B, "frames": FRAMES, "samples_per_utterance": FRAMES * engine.samples_per_frame,
                    "operands": {"f16": "f16 MFMA operands, fp32 accumulate", "bf16": "bf16 MFMA operands, fp32 accumulate",
                                 "bf16x": "bf16 MFMA operands in the fused ResBlock pairs (80 % of the FLOPs) with an f16 residual stream, f16 operands elsewhere, fp32 accumulate"}[args.dtype], "hipgraph": graph is not None,
-                   "parallel_resblock_branches": args.branches,
+                   "parallel_resblock_branches": False,     # set below from the launch records: only unfused stages fork
                    "parallelism": f"utterance-sharded x{world}, no per-step collective"},
         "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
         "steady_state": steady,
@@ -178,6 +208,13 @@ def main() -> None:
                     a = agg.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
                     a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
                     total_ms += r["ms"]
+        # the fork / join path exists only for stages whose ResBlock pairs do not run fused (qvc_plan_info()[7])
+        import ctypes
+        info = (ctypes.c_int32 * 8)()
+        engine.lib.qvc_plan_info(ctypes.byref(engine.cfg), info)
+        result["config"]["parallel_resblock_branches"] = bool(args.branches and not info[7])
+        if args.branches and info[7]:
+            print("bench.py: --branches has no effect on this configuration (every stage runs its three chains fused in one launch)", file=sys.stderr)
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_bench.sh writes

@@ -120,6 +120,11 @@ int qvc_device_check(void);
  * "wn_kernel".  Unknown name: QVC_ERR_BAD_ARG.  No reference counterpart. */
 int qvc_debug_set(const char* name, int32_t value);
 int qvc_debug_get(const char* name, int32_t* value);
+/* fp32 -> f16 conversions that SATURATED (|x| > 65504) since the last reset, summed over all kernels.  Counted only
+ * by the debug build libqvc_hip_sat.so (-DQVC_SATCOUNT; synchronises the device): an activation range the f16
+ * streams cannot carry becomes a number instead of passing silently.  The product library spends no instruction on
+ * it and returns QVC_ERR_BAD_CONFIG with *count = -1. */
+int qvc_debug_saturations(int64_t* count, int32_t reset);
 
 /* ---- weights: replaces nn.Module.load_state_dict + per-forward weight_norm ----
  * Reference: utils.py:148-180 (load), modules.py:54,64,67,134-143 and
@@ -142,6 +147,11 @@ int qvc_pack_weights(const qvc_config* cfg, const qvc_tensor* tensors, int32_t n
  *   out   (B, T*prod(ups)*hop*subbands) fp32 waveform = (B,1,320*T)
  */
 int64_t qvc_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t frames);
+/* Layout decisions the plan takes for `cfg` (diagnostics; no reference counterpart): info[0] enc_p.proj rows paired
+ * [mu | log sigma] (sampling in the conv epilogue), [1] its fragments per wave, [2..3] up-samplers 0 / 1 lane-packed,
+ * [4] conv_post + iSTFT / band synthesis can run as one launch, [5..6] waves per workgroup of the stage 0 / 1 ResBlock
+ * pairs, [7] every ResBlock pair runs fused, three chains per launch (then qvc_aux branches are never taken). */
+int qvc_plan_info(const qvc_config* cfg, int32_t info[8]);
 int qvc_infer_batch(const qvc_config* cfg, const void* blob_dev,
                     const float* unit, const float* g, const float* noise, float* out,
                     int32_t batch, int32_t frames,

@@ -40,6 +40,9 @@ int qvc_io_pool_destroy(qvc_io_pool* pool);
 /* Shape of a unit file from its header alone (no payload is read): dataset/encode.py:38 writes (frames, 256). */
 int qvc_io_npy_shape(const char* path, int32_t* frames, int32_t* cols);
 
+/* The same for n files at once, on the pool (planning a corpus run reads every header once). */
+int qvc_io_npy_shapes(qvc_io_pool* pool, const char* const* paths, int32_t n, int32_t* frames, int32_t* cols);
+
 /* Read n unit files into a batch buffer, FRAME-MAJOR as they are on disk: file i's (frames_i, cols) array lands at
  * dst + i * slot_frames * cols (row pitch = cols floats); rows past frames_i are left untouched (the ragged kernels
  * never read them).  frames_out[i] = frames_i.  Fails with QVC_IO_ERR_SHAPE if a file has another column count or

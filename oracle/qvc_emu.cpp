@@ -344,6 +344,12 @@ struct EmuBackend {
     for (int i = 0; i < a.n; ++i) pair(d1[i], d2[i], a.p[i], B, dtype, a.rg);
     return QVC_OK;
   }
+  // a whole ResBlock in one launch (qvc_chain_impl.h): replayed pair by pair through the buffers the arguments name
+  bool chain_ok(const ConvDesc* d1, const ConvDesc* d2, int n) const { return chain_supported(d1, d2, n); }
+  int chain(const ConvDesc* d1, const ConvDesc* d2, const ChainArgs& a, int B, int dtype) {
+    for (int q = 0; q < a.n; ++q) pair(d1[q], d2[q], a.p[q], B, dtype, a.rg);
+    return QVC_OK;
+  }
   int gemv(const GemvArgs& a) {
     for (int b = 0; b < a.batch; ++b)
       for (int r = 0; r < a.rows; ++r) {

@@ -15,6 +15,13 @@
 
 namespace qvc {
 int launch_fm_to_cm(const float* src, float* dst, int batch, int frames, int channels, void* stream);
+#ifdef QVC_SATCOUNT
+unsigned long long sat_count_conv_f16(bool reset);
+unsigned long long sat_count_conv_bf16(bool reset);
+unsigned long long sat_count_wn2(bool reset);
+unsigned long long sat_count_spk(bool reset);
+unsigned long long sat_count_chain(bool reset);
+#endif
 }
 
 struct qvc_aux {
@@ -71,6 +78,8 @@ struct HipBackend {
   int conv(const ConvDesc& d, const ConvArgs& a, int batch, int epi, int dtype) { return launch_conv(d, a, batch, epi, dtype, stream); }
   int pair(const ConvDesc& d1, const ConvDesc& d2, const PairArgs& a, int batch, int dtype) { return launch_pair(d1, d2, a, batch, dtype, stream); }
   int pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype) { return launch_pair3(d1, d2, a, batch, dtype, stream); }
+  bool chain_ok(const ConvDesc* d1, const ConvDesc* d2, int n) const { return debug_get(DBG_PAIR_CHAIN3) != 0 && chain_supported(d1, d2, n); }
+  int chain(const ConvDesc* d1, const ConvDesc* d2, const ChainArgs& a, int batch, int dtype) { return launch_chain(d1, d2, a, batch, dtype, stream); }
   int wn(const ConvDesc& din, const ConvDesc&, const WnArgs& a, int batch, int dtype) { return launch_wn(din, a, batch, dtype, stream); }
   // the stack kernel recomputes halo frames but a layer is bound by its weight stream, not by MFMA work: measured
   // no slower than one launch per layer at any batch (16.4 vs 17.9 us per layer at batch 1)
@@ -147,6 +156,19 @@ struct TimedBackend {
       by += outs * 2 * 3 + (double)d1[i].w_bytes() + (double)d2[i].w_bytes();
     }
     note(name, fl, by);
+    return st;
+  }
+  bool chain_ok(const ConvDesc* d1, const ConvDesc* d2, int n) const { return debug_get(DBG_PAIR_CHAIN3) != 0 && chain_supported(d1, d2, n); }
+  int chain(const ConvDesc* d1, const ConvDesc* d2, const ChainArgs& a, int batch, int dtype) {
+    if (ev.empty()) mark();
+    int nf = 0;
+    int st = launch_chain(d1, d2, a, batch, dtype, stream, &nf);
+    mark();
+    char name[48];
+    const char* tn = dtype == QVC_F16 ? "f16" : (dtype == QVC_BF16X ? "bf16x" : "bf16");
+    std::snprintf(name, sizeof(name), "rbchain<%s,MF%d,NF%d,WM%d,k%d>", tn, d1[0].MF, nf, d1[0].WM, d1[0].taps);
+    const double outs = (double)batch * a.p[0].T * a.p[0].C;
+    note(name, a.n * 2.0 * 2.0 * outs * a.p[0].C * a.p[0].k, outs * 2 * 2 + a.n * ((double)d1[0].w_bytes() + (double)d2[0].w_bytes()));
     return st;
   }
   int wn(const ConvDesc& din, const ConvDesc& drs, const WnArgs& a, int batch, int dtype) {
@@ -271,6 +293,22 @@ int qvc_debug_get(const char* name, int32_t* value) {
   return QVC_ERR_BAD_ARG;
 }
 
+int qvc_debug_saturations(int64_t* count, int32_t reset) {
+  if (!count) return QVC_ERR_BAD_ARG;
+#ifdef QVC_SATCOUNT
+  const unsigned long long v[5] = {sat_count_conv_f16(reset != 0), sat_count_conv_bf16(reset != 0), sat_count_wn2(reset != 0), sat_count_spk(reset != 0),
+                                   sat_count_chain(reset != 0)};
+  unsigned long long sum = 0;
+  for (unsigned long long x : v) { if (x == ~0ull) return QVC_ERR_LAUNCH; sum += x; }
+  *count = (int64_t)sum;
+  return QVC_OK;
+#else
+  (void)reset;
+  *count = -1;
+  return QVC_ERR_BAD_CONFIG;      // the product library does not count (no instruction is spent on it)
+#endif
+}
+
 int qvc_device_check(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return QVC_ERR_NO_DEVICE;
@@ -286,6 +324,25 @@ int64_t qvc_workspace_bytes(const qvc_config* cfg, int32_t batch, int32_t frames
   Plan P = build_plan(*cfg);
   if (P.status != QVC_OK) return P.status;
   return carve_workspace(P, batch, frames).bytes;
+}
+
+int qvc_plan_info(const qvc_config* cfg, int32_t info[8]) {
+  if (!cfg || !info) return QVC_ERR_BAD_ARG;
+  const Plan P = build_plan(*cfg);
+  if (P.status != QVC_OK) return P.status;
+  for (int i = 0; i < 8; ++i) info[i] = 0;
+  info[0] = P.enc_proj.gau; info[1] = P.enc_proj.MF;
+  for (size_t i = 0; i < P.stages.size() && i < 2; ++i) {
+    info[2 + i] = P.stages[i].up.lp;
+    info[5 + i] = block_waves(P.stages[i].c1[0]);
+  }
+  info[4] = post_tail_supported(P.conv_post) ? 1 : 0;
+  int all = P.cfg.n_resblocks <= 3 ? 1 : 0;
+  for (const StagePlan& st : P.stages)
+    for (size_t j = 0; j < st.c1.size(); ++j)
+      all = all && pair_supported(st.c1[j], st.c2[j]) && st.c1[j].lp && st.c2[j].lp && st.c1[j].MF == st.c1[0].MF && st.c1[j].WM == st.c1[0].WM;
+  info[7] = all;
+  return QVC_OK;
 }
 
 int qvc_aux_create(qvc_aux** out) {

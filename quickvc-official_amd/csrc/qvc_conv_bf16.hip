@@ -8,3 +8,6 @@ template int launch_wn_typed<__bf16>(const ConvDesc&, const WnArgs&, int, void*,
 template int launch_pair_typed<__bf16, __bf16>(const ConvDesc*, const PairArgs3&, int, void*, int*);
 // QVC_BF16X: bf16 operands, f16 residual stream
 template int launch_pair_typed<__bf16, _Float16>(const ConvDesc*, const PairArgs3&, int, void*, int*); }
+#ifdef QVC_SATCOUNT
+namespace qvc { QVC_SAT_READER(sat_count_conv_bf16) }
+#endif

@@ -7,3 +7,6 @@ template int launch_post_tail_typed<_Float16>(const ConvDesc&, const PostTailArg
 template int launch_wn_stack_typed<_Float16>(const ConvDesc&, const WnStackArgs&, int, void*);
 template int launch_wn_typed<_Float16>(const ConvDesc&, const WnArgs&, int, void*, int*);
 template int launch_pair_typed<_Float16, _Float16>(const ConvDesc*, const PairArgs3&, int, void*, int*); }
+#ifdef QVC_SATCOUNT
+namespace qvc { QVC_SAT_READER(sat_count_conv_f16) }
+#endif

@@ -32,6 +32,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Debug build only (-DQVC_SATCOUNT, libqvc_hip_sat.so; never defined in the product library): every fp32 -> f16
+// conversion that saturates counts itself, so that an activation range the f16 streams cannot carry shows up as a
+// number (qvc_debug_saturations) instead of passing silently.  One counter per translation unit (internal linkage).
+#ifdef QVC_SATCOUNT
+static __device__ unsigned long long g_sat_count = 0;
+#define QVC_SAT_READER(name)                                                                        \
+  unsigned long long name(bool reset) {                                                             \
+    unsigned long long v = 0, z = 0;                                                                \
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sat_count), 8) != hipSuccess) return ~0ull;            \
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_sat_count), &z, 8) != hipSuccess) return ~0ull;     \
+    return v;                                                                                       \
+  }
+#endif
+
 template <typename T> struct Op;
 template <> struct Op<_Float16> {
   using frag = f16x8; using quad = f16x4;
@@ -39,6 +53,9 @@ template <> struct Op<_Float16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ _Float16 cvt(float f) {
+#ifdef QVC_SATCOUNT
+    if (__builtin_fabsf(f) > 65504.f) atomicAdd(&g_sat_count, 1ull);
+#endif
     return (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);   // saturate instead of inf
   }
 };
@@ -114,7 +131,7 @@ __device__ __forceinline__ f16x8 lrelu8<_Float16>(f16x8 v, float slope) {
 // developer phase stamps for tools/conv_bench (never defined in the product build): s_memtime at the phase boundaries of
 // the WaveNet stack kernel, written to WnStackArgs::stamps [workgroup][wave][32] at the end of the kernel
 #ifdef QVC_STAMP
-#define QVC_ST(slot) (st_[slot] = __builtin_amdgcn_s_memtime())
+#define QVC_ST(slot) do { if (st_ && lane == 0) st_[slot] = __builtin_amdgcn_s_memtime(); } while (0)   // straight to memory: a local array would live in scratch
 #else
 #define QVC_ST(slot) ((void)0)
 #endif
@@ -944,8 +961,8 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * OUTF;
 #ifdef QVC_STAMP
-  unsigned long long st_[32] = {};
-  st_[27] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long* const st_ = a.stamps ? a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wm) * 32 : nullptr;
+  if (st_ && lane == 0) st_[27] = __builtin_amdgcn_s_memrealtime();
 #endif
   QVC_ST(0);
   const int Tb = ragged_len(a.rg, b, a.T);    // this utterance occupies rows [Tlo, Tb): x is zero outside at every layer
@@ -1227,12 +1244,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
   }
 #ifdef QVC_STAMP
   QVC_ST(26);
-  st_[28] = __builtin_amdgcn_s_memrealtime();
-  if (a.stamps && lane == 0) {
-    unsigned long long* dst = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wm) * 32;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) dst[i] = st_[i];
-  }
+  if (st_ && lane == 0) st_[28] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

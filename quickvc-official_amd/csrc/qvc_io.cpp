@@ -197,6 +197,20 @@ int qvc_io_npy_shape(const char* path, int32_t* frames, int32_t* cols) {
   return QVC_IO_OK;
 }
 
+int qvc_io_npy_shapes(qvc_io_pool* pool, const char* const* paths, int32_t n, int32_t* frames, int32_t* cols) {
+  if (!pool || !paths || !frames || !cols || n < 0) return QVC_IO_ERR_BAD_ARG;
+  // headers are tiny: hand each worker a run of files instead of one job per file
+  const int per = 64, jobs = (n + per - 1) / per;
+  return pool->run(jobs, [=](int j) -> int {
+    int rc = QVC_IO_OK;
+    for (int i = j * per; i < n && i < (j + 1) * per; ++i) {
+      const int r = paths[i] ? qvc_io_npy_shape(paths[i], frames + i, cols + i) : QVC_IO_ERR_BAD_ARG;
+      if (r != QVC_IO_OK && rc == QVC_IO_OK) rc = r;
+    }
+    return rc;
+  });
+}
+
 int qvc_io_load_units(qvc_io_pool* pool, const char* const* paths, int32_t n, float* dst, int32_t slot_frames, int32_t cols,
                       int32_t* frames_out) {
   if (!pool || !paths || !dst || !frames_out || n < 0 || slot_frames <= 0 || cols <= 0) return QVC_IO_ERR_BAD_ARG;

@@ -1,5 +1,6 @@
 // qvc_kernels.h -- launch-side view of the gfx950 kernels (arguments + launcher prototypes).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include "qvc_plan.h"
@@ -107,6 +108,57 @@ struct PairArgs3 {
   int32_t chain_major = 0;
 };
 
+// A whole ResBlock1 -- n chained pairs (dilations d_0 .. d_{n-1}) -- in ONE launch (qvc_chain_impl.h), for chains whose
+// receptive field is short: p[0].x is read once (tile + halo), p[n-1].y written once, the stream stays on chip in
+// between.  p[q].x / p[q].y of the inner pairs are the buffers the pair-by-pair path would use (the host emulation
+// replays the chain that way).  halo / margin / NT are filled by the launcher (chain_geom).
+struct ChainArgs {
+  PairArgs p[3];
+  int32_t n = 3;
+  Ragged rg;
+  int32_t halo = 0, margin = 0, NT = 0;
+};
+
+struct ChainGeom { int halo, margin, NT; size_t lds; };
+// tile of NF fragments (NF * 16 rows): halo rows per side are recomputed, NT = rows - 2 * halo frames come out
+inline ChainGeom chain_geom(const ConvDesc* d1, int n, int NF) {
+  ChainGeom g{0, 0, 0, 0};
+  for (int q = 0; q < n; ++q) {
+    const int h = (d1[q].taps - 1) / 2;
+    g.halo += h * (d1[q].dil + 1);
+    g.margin = std::max(g.margin, h * d1[q].dil);
+  }
+  g.NT = NF * 16 - 2 * g.halo;
+  g.lds = (size_t)(NF * 16 + 2 * g.margin + NF * 16) * d1[0].CinP * 2;
+  return g;
+}
+
+// Tile choice: the largest tile (fewest recomputed halo frames per produced frame) whose LDS fits the occupancy the
+// layout's pair kernel has -- two 4-wave workgroups or one 8-wave workgroup per CU.
+inline int chain_pick_nf(const ConvDesc* d1, int n, ChainGeom* out) {
+  const int nwv = block_waves(d1[0]);
+  const size_t budget = nwv == 8 ? 160 * 1024 : 80 * 1024;
+  static const int nfs[] = {9, 8, 6, 5, 4};
+  for (int NF : nfs) {
+    if (d1[0].MF * NF * 4 > (d1[0].MF > 2 ? 80 : 96)) continue;  // accumulator registers (+ as many for the B double buffer)
+    const ChainGeom g = chain_geom(d1, n, NF);
+    if (g.lds <= budget && g.NT >= 64 && 4 * 2 * g.halo <= NF * 16) { *out = g; return NF; }   // <= 25 % of the tile recomputed ...
+  }
+  return 0;
+}
+
+inline bool chain_supported(const ConvDesc* d1, const ConvDesc* d2, int n) {
+  if (n < 2 || n > 3) return false;
+  for (int q = 0; q < n; ++q) {
+    if (!pair_supported(d1[q], d2[q]) || !d1[q].lp || !d2[q].lp) return false;
+    if (d1[q].MF != d1[0].MF || d1[q].WM != d1[0].WM || d1[q].CinP != d1[0].CinP || d1[q].taps != d1[0].taps || d1[q].M != d1[0].M) return false;
+  }
+  const int nwv = block_waves(d1[0]);
+  if (d1[0].MF % 2 || nwv != d1[0].WM) return false;             // all waves along the rows, 16-byte epilogue pieces
+  ChainGeom g;
+  return chain_pick_nf(d1, n, &g) != 0;
+}
+
 // One fused WaveNet layer (modules.py:87-112): k-tap conv h->2h + conditioning + tanh*sigmoid gate, then the
 // 1x1 h->2h whose first half is added to the residual stream x and second half to the skip accumulator
 // (all of it to the accumulator on the last layer).  x is ping-ponged (x_in -> x_out) because neighbouring
@@ -209,12 +261,13 @@ enum DebugSwitch : int32_t {
   DBG_PAIR_CM4,             // 1 (default): chain-major grid for three-chain launches of 4-wave layouts; 0: chains interleaved (x % n)
   DBG_CONV_CL,              // 1 (default): chunk-loop variant of the conv kernel where it applies; 0: one workgroup per row chunk
   DBG_WN_CHUNK,             // 0 (default): 4 WaveNet layers per stack launch; n > 0: n layers; -1: one launch per layer, pre / post as convs
-  DBG_PAIR_CHAIN3,          // 1 (default): the three pairs of a short-kernel ResBlock chain in one launch where supported; 0: off
+  DBG_PAIR_CHAIN3,          // 0 (default): off; 1: the three pairs of a short-kernel ResBlock chained in one launch (qvc_chain_impl.h:
+                            //    bit-identical, measured SLOWER -- the k 3 pairs cost less riding in the three-chain launches)
   DBG_WN_KERNEL,            // WaveNet stack kernel variant (0 = default)
   DBG_COUNT
 };
 inline std::atomic<int32_t>* debug_table() {
-  static std::atomic<int32_t> t[DBG_COUNT] = {{1}, {4}, {1}, {1}, {1}, {0}, {1}, {0}};
+  static std::atomic<int32_t> t[DBG_COUNT] = {{1}, {4}, {1}, {1}, {1}, {0}, {0}, {0}};
   return t;
 }
 inline int debug_get(int which) { return debug_table()[which].load(std::memory_order_relaxed); }
@@ -228,6 +281,8 @@ int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, vo
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 // n pairs (1..3) of equal shape class in one launch; d1[i] / d2[i] are chain i's convs
 int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int batch, int dtype, void* stream, int* nf_out = nullptr);
+// the n pairs of one ResBlock chained in one launch (chain_supported() says when); d1[q] / d2[q] are pair q's convs
+int launch_chain(const ConvDesc* d1, const ConvDesc* d2, const ChainArgs& a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 bool wn_stack_supported(const ConvDesc& din, int layers);
 int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dtype, void* stream);
 int wn_stack_variant(const ConvDesc& din, const WnStackArgs& a);   // 2: the continuous-stream kernel (qvc_wn2_impl.h), 1: the generic one
@@ -242,6 +297,7 @@ template <typename T> int launch_conv_typed(const ConvDesc& d, const ConvArgs& a
 template <typename T> int launch_wn_stack_typed(const ConvDesc& din, const WnStackArgs& a, int batch, void* stream);
 template <typename T> int launch_wn_typed(const ConvDesc& din, const WnArgs& a, int batch, void* stream, int* nf_out);
 template <typename T> int launch_post_tail_typed(const ConvDesc& d, const PostTailArgs& a, int batch, void* stream);
+template <typename T, typename TS> int launch_chain_typed(const ConvDesc* d1, const ConvDesc* d2, ChainArgs a, int batch, void* stream, int* nf_out);
 template <typename T, typename TS> int launch_pair_typed(const ConvDesc* d1, const PairArgs3& a, int batch, void* stream, int* nf_out);   // TS: stream type
 
 }  // namespace qvc

@@ -331,16 +331,43 @@ struct Path {
       const bool wide = block_waves(st.c1[0]) != kWaves;
       const int per_launch = (!wide || few_tiles || debug_get(DBG_PAIR_WIDE_LAUNCH)) ? NB : 1;   // 0: one chain per launch
       const int chain_major = ((wide || debug_get(DBG_PAIR_CM4)) && !few_tiles) ? 1 : 0;           // 0: 4-wave layouts interleave the chains (x % n)
+      // A ResBlock with a short kernel (k 3: 12 frames of receptive field per side) runs as ONE launch, its three
+      // pairs chained on chip (qvc_chain_impl.h): its stream is read once and written once instead of three times
+      // each.  The other chains keep the pair-by-pair launches.  (Tiny batches: everything in the time of the longest
+      // chain is better, see below.)
+      bool chained[3] = {false, false, false};
+      if (fused && !few_tiles) {
+        for (int j = 0; j < NB; ++j) {
+          ConvDesc d1s[3], d2s[3];
+          for (int q = 0; q < 3; ++q) { d1s[q] = st.c1[(size_t)j * 3 + q]; d2s[q] = st.c2[(size_t)j * 3 + q]; }
+          if (!be.chain_ok(d1s, d2s, 3)) continue;
+          ChainArgs ca; ca.n = 3; ca.rg = rg(rate);
+          const void* cur = wsp<void>(W.u[i]);
+          for (int q = 0; q < 3; ++q) {
+            void* dst = q == 1 ? wsp<void>(W.rb[i][(size_t)j]) : wsp<void>(W.ra[i][(size_t)j]);
+            src[(size_t)j] = cur;
+            ca.p[q] = pair_args(j, q, dst);
+            cur = dst;
+          }
+          src[(size_t)j] = cur;
+          if (status == QVC_OK) status = be.chain(d1s, d2s, ca, B, dtype_pair());
+          chained[j] = true;
+        }
+      }
       if (fused) {
-        for (int q = 0; q < 3; ++q) for (int j0 = 0; j0 < NB; j0 += per_launch) {
+        int rest[3], n_rest = 0;
+        for (int j = 0; j < NB; ++j) if (!chained[j]) rest[n_rest++] = j;
+        for (int q = 0; q < 3 && n_rest > 0; ++q) for (int j0 = 0; j0 < n_rest; j0 += (per_launch < n_rest ? per_launch : n_rest)) {
+          const int per_launch_q = per_launch < n_rest ? per_launch : n_rest;
           // stream of ResBlock j: u -> ra -> rb -> ra; the MRF mean of the three final tensors is taken by the
           // consumer (next up-sampler / conv_post) while it stages its input, so nothing is accumulated here
-          PairArgs3 a3; a3.n = per_launch; a3.rg = rg(rate); a3.chain_major = per_launch > 1 ? chain_major : 0;
+          PairArgs3 a3; a3.n = per_launch_q; a3.rg = rg(rate); a3.chain_major = per_launch_q > 1 ? chain_major : 0;
           ConvDesc d1s[3], d2s[3];
           // the chain with the largest kernel first: its workgroups are the longest, so they should start earliest
-          int order[3] = {j0, j0 + 1, j0 + 2};
-          std::sort(order, order + per_launch, [&](int x, int y) { return st.c1[(size_t)x * 3 + q].nIt() > st.c1[(size_t)y * 3 + q].nIt(); });
-          for (int s_ = 0; s_ < per_launch; ++s_) {
+          int order[3] = {0, 0, 0};
+          for (int s_ = 0; s_ < per_launch_q; ++s_) order[s_] = rest[j0 + s_];
+          std::sort(order, order + per_launch_q, [&](int x, int y) { return st.c1[(size_t)x * 3 + q].nIt() > st.c1[(size_t)y * 3 + q].nIt(); });
+          for (int s_ = 0; s_ < per_launch_q; ++s_) {
             const int j = order[s_];
             void* dst = q == 1 ? wsp<void>(W.rb[i][(size_t)j]) : wsp<void>(W.ra[i][(size_t)j]);
             a3.p[s_] = pair_args(j, q, dst);

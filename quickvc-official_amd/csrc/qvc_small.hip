@@ -305,6 +305,16 @@ int launch_pair3(const ConvDesc* d1, const ConvDesc* d2, const PairArgs3& a, int
   return QVC_ERR_BAD_ARG;
 }
 
+int launch_chain(const ConvDesc* d1, const ConvDesc* d2, const ChainArgs& a, int batch, int dtype, void* stream, int* nf_out) {
+  if (!chain_supported(d1, d2, a.n)) return QVC_ERR_BAD_CONFIG;
+  for (int q = 1; q < a.n; ++q)
+    if (a.p[q].T != a.p[0].T || a.p[q].C != a.p[0].C || a.p[q].CP != a.p[0].CP || a.p[q].bs != a.p[0].bs) return QVC_ERR_BAD_ARG;
+  if (dtype == QVC_F16) return launch_chain_typed<_Float16, _Float16>(d1, d2, a, batch, stream, nf_out);
+  if (dtype == QVC_BF16) return launch_chain_typed<__bf16, __bf16>(d1, d2, a, batch, stream, nf_out);
+  if (dtype == QVC_BF16X) return launch_chain_typed<__bf16, _Float16>(d1, d2, a, batch, stream, nf_out);
+  return QVC_ERR_BAD_ARG;
+}
+
 int launch_pair(const ConvDesc& d1, const ConvDesc& d2, PairArgs a, int batch, int dtype, void* stream, int* nf_out) {
   PairArgs3 a3; a3.p[0] = a; a3.n = 1;
   return launch_pair3(&d1, &d2, a3, batch, dtype, stream, nf_out);

@@ -300,3 +300,6 @@ extern "C" int qvc_speaker_embed(const qvc_config* cfg, const void* spk_blob_dev
   return spk_path(S, dec_dtype(*cfg), static_cast<const char*>(spk_blob_dev), static_cast<char*>(workspace), W, mel, g,
                   U, F, be);
 }
+#ifdef QVC_SATCOUNT
+namespace qvc { QVC_SAT_READER(sat_count_spk) }
+#endif

@@ -6,3 +6,6 @@ template int launch_wn_stack2_typed<_Float16>(const ConvDesc&, const WnStackArgs
 template int launch_wn_stack2_typed<__bf16>(const ConvDesc&, const WnStackArgs&, int, void*);
 bool wn_stack2_supported(const ConvDesc& din, const WnStackArgs& a) { return wn2_supported(din, a); }
 }  // namespace qvc
+#ifdef QVC_SATCOUNT
+namespace qvc { QVC_SAT_READER(sat_count_wn2) }
+#endif

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * OUTF;
 #ifdef QVC_STAMP
-  unsigned long long st_[32] = {};
-  st_[27] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long* const st_ = a.stamps ? a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wm) * 32 : nullptr;
+  if (st_ && lane == 0) st_[27] = __builtin_amdgcn_s_memrealtime();
 #endif
   QVC_ST(0);
   const int Tb = ragged_len(a.rg, b, a.T);
@@ -390,12 +390,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
   }
 #ifdef QVC_STAMP
   QVC_ST(26);
-  st_[28] = __builtin_amdgcn_s_memrealtime();
-  if (a.stamps && lane == 0) {
-    unsigned long long* dst = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wm) * 32;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) dst[i] = st_[i];
-  }
+  if (st_ && lane == 0) st_[28] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

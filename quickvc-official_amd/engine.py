@@ -37,7 +37,10 @@ def _on_device(fn):
 
 
 class QvcEngine:
-    def __init__(self, model_config: dict, state_dict: Dict[str, torch.Tensor], device, parallel_branches: bool = False):
+    def __init__(self, model_config: dict, state_dict: Optional[Dict[str, torch.Tensor]], device, parallel_branches: bool = False,
+                 pack: bool = True):
+        """``pack=False`` (multi-GPU start-up, ranks other than the one that owns the checkpoint): allocate the blob
+        without packing anything -- ``state_dict`` may be None -- and let ``dist.broadcast_blob`` fill it."""
         self.lib = L.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -46,9 +49,16 @@ class QvcEngine:
             L.check(self.lib, self.lib.qvc_device_check(), "qvc_device_check")
         self.model_config = dict(model_config)
         self.cfg = L.make_config(model_config)
-        host_blob = L.pack_weights(self.lib, self.cfg, state_dict)
-        self.blob = _aligned_empty(host_blob.numel(), self.device)
-        self.blob.copy_(host_blob)
+        if pack:
+            host_blob = L.pack_weights(self.lib, self.cfg, state_dict)
+            self.blob = _aligned_empty(host_blob.numel(), self.device)
+            self.blob.copy_(host_blob)
+        else:
+            n = int(self.lib.qvc_blob_bytes(ctypes.byref(self.cfg)))
+            if n < 0:
+                L.check(self.lib, n, "qvc_blob_bytes")
+            self.blob = _aligned_empty(n, self.device)
+            state_dict = state_dict or {}
         # optional fork/join resources: the three ResBlocks of a stage as parallel branches (two aux streams +
         # events).  Measured neutral on MI355X (2.934 vs 2.949 ms/step: each launch already fills the chip), and
         # concurrent kernels blur per-kernel profiles, so it is off by default.
@@ -129,12 +139,18 @@ class QvcEngine:
 
     @_on_device
     def infer_batch_ragged(self, unit: torch.Tensor, g: torch.Tensor, noise: torch.Tensor, frames: torch.Tensor,
-                           out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                           unit_fm: bool = False) -> torch.Tensor:
         """A batch of utterances of DIFFERENT lengths: unit (B,256,Tmax) / noise (B,inter,Tmax) padded (the padding's
         content is ignored), frames (B,) int32 lengths -> (B,1,Tmax*samples_per_frame); row b holds utterance b's
-        waveform in its first frames[b]*samples_per_frame samples and zeros after."""
-        B, cu, T = unit.shape
+        waveform in its first frames[b]*samples_per_frame samples and zeros after.
+        ``unit_fm``: unit is (B,Tmax,256) -- frame-major, as the reference's unit files are on disk
+        (dataset/encode.py:38), so a batch read by fileio.IoPool.load_units uploads as it is."""
         mc = self.model_config
+        if unit_fm:
+            B, T, cu = unit.shape
+        else:
+            B, cu, T = unit.shape
         if cu != mc.get("unit_channels", 256) or g.shape != (B, mc["gin_channels"]) or \
                 tuple(noise.shape) != (B, mc["inter_channels"], T) or tuple(frames.shape) != (B,):
             raise ValueError(f"bad input shapes: unit {tuple(unit.shape)}, g {tuple(g.shape)}, noise {tuple(noise.shape)}, frames {tuple(frames.shape)}")
@@ -147,9 +163,10 @@ class QvcEngine:
             out = torch.empty(B, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
         if ws is None:
             ws = self.workspace(B, T)
-        st = self.lib.qvc_infer_batch_ragged(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
-                                             noise.data_ptr(), out.data_ptr(), B, T, lens.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             torch.cuda.current_stream(self.device).cuda_stream)
+        fn = self.lib.qvc_infer_batch_ragged_fm if unit_fm else self.lib.qvc_infer_batch_ragged
+        st = fn(ctypes.byref(self.cfg), self.blob.data_ptr(), unit.data_ptr(), g.data_ptr(),
+                noise.data_ptr(), out.data_ptr(), B, T, lens.data_ptr(), ws.data_ptr(), ws.numel(),
+                torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib, st, "qvc_infer_batch_ragged")
         return out
 

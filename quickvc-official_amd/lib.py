@@ -63,10 +63,14 @@ def declare(lib: ctypes.CDLL, prefix: str = "qvc") -> None:
         lib.qvc_debug_set.argtypes = [ctypes.c_char_p, I]
         lib.qvc_debug_get.restype = ctypes.c_int
         lib.qvc_debug_get.argtypes = [ctypes.c_char_p, P(I)]
+        lib.qvc_debug_saturations.restype = ctypes.c_int
+        lib.qvc_debug_saturations.argtypes = [P(L), I]
         lib.qvc_blob_bytes.restype = L
         lib.qvc_blob_bytes.argtypes = [cfgp]
         lib.qvc_pack_weights.restype = ctypes.c_int
         lib.qvc_pack_weights.argtypes = [cfgp, P(QvcTensor), I, V, L]
+        lib.qvc_plan_info.restype = ctypes.c_int
+        lib.qvc_plan_info.argtypes = [cfgp, P(I)]
         lib.qvc_workspace_bytes.restype = L
         lib.qvc_workspace_bytes.argtypes = [cfgp, I, I]
         lib.qvc_infer_batch.restype = ctypes.c_int

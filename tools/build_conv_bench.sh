@@ -13,11 +13,12 @@ if [ -n "$PF_CONV$PF_WN$EXTRA" ]; then
   # every translation unit that sees the kernel argument structs gets the same defines
   $H $X -c $C/qvc_conv_f16.hip -o $O/qvc_conv_f16_$TAG.o &
   $H $X -c $C/qvc_wn2.hip -o $O/qvc_wn2_$TAG.o &
+  $H $X -c $C/qvc_chain.hip -o $O/qvc_chain_$TAG.o &
   $H $X -c $C/qvc_small.hip -o $O/qvc_small_$TAG.o &
   $H $X -c tools/conv_bench.hip -o $O/conv_bench_$TAG.o &
   wait
-  $H $O/conv_bench_$TAG.o $O/qvc_conv_f16_$TAG.o $O/qvc_wn2_$TAG.o $O/qvc_conv_bf16.o $O/qvc_small_$TAG.o $O/qvc_pack.o -o tools/conv_bench_$TAG
+  $H $O/conv_bench_$TAG.o $O/qvc_conv_f16_$TAG.o $O/qvc_wn2_$TAG.o $O/qvc_chain_$TAG.o $O/qvc_conv_bf16.o $O/qvc_small_$TAG.o $O/qvc_pack.o -o tools/conv_bench_$TAG
   exit 0
 fi
 $H -c tools/conv_bench.hip -o $O/conv_bench.o
-$H $O/conv_bench.o $O/qvc_conv_f16.o $O/qvc_wn2.o $O/qvc_conv_bf16.o $O/qvc_small.o $O/qvc_pack.o -o tools/conv_bench
+$H $O/conv_bench.o $O/qvc_conv_f16.o $O/qvc_wn2.o $O/qvc_chain.o $O/qvc_conv_bf16.o $O/qvc_small.o $O/qvc_pack.o -o tools/conv_bench

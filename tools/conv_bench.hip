@@ -194,6 +194,18 @@ int main(int argc, char** argv) {
         }
         printf(" tail %llu\n", t[26] - t[25]);
       }
+      {   // wave start times (s_memrealtime, 100 MHz) relative to the launch's earliest wave: launch skew inside a workgroup and over the grid
+        unsigned long long tmin = ~0ull, tmaxend = 0;
+        for (int wg = 0; wg < nwg; ++wg) for (int wv = 0; wv < 12; ++wv) { const unsigned long long* t = &hs[((size_t)wg * 16 + wv) * 32]; if (t[27] && t[27] < tmin) tmin = t[27]; if (t[28] > tmaxend) tmaxend = t[28]; }
+        printf("launch: first wave start -> last wave end %.2f us\n", (double)(tmaxend - tmin) * 0.01);
+        for (int wg : {0, 1, 8, nwg / 3, nwg - 1}) {
+          printf("start offsets wg %3d (us):", wg);
+          for (int wv = 0; wv < 12; ++wv) printf(" %.2f", (double)(hs[((size_t)wg * 16 + wv) * 32 + 27] - tmin) * 0.01);
+          printf("  | end:");
+          for (int wv = 0; wv < 12; wv += 11) printf(" %.2f", (double)(hs[((size_t)wg * 16 + wv) * 32 + 28] - tmin) * 0.01);
+          printf("\n");
+        }
+      }
       // mean over all workgroups and waves of each phase
       double sum[26] = {0}; int cnt = 0;
       for (int wg = 0; wg < nwg; ++wg) for (int wv = 0; wv < 12; ++wv) {
