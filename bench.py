@@ -85,6 +85,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches (only stages whose pairs do NOT run fused take that path)")
+    ap.add_argument("--debug", action="append", default=[], metavar="NAME=VALUE",
+                    help="developer switch of the library (qvc_debug_set), e.g. pair_chain3=1, wn_kernel=1: for A/B runs of variants "
+                         "that give identical results; recorded in the JSON line")
     ap.add_argument("--rehearsal", action="store_true",
                     help="developer switch for a 1-GPU box: every rank on cuda:0 with gloo, to exercise the multi-rank control flow")
     args = ap.parse_args()
@@ -121,6 +124,10 @@ def main() -> None:
     # rank 0 owns the checkpoint and packs it; everybody else allocates an empty blob and receives it in ONE broadcast
     sd = make_synthetic_state_dict(model, 1234) if rank == 0 else None
     engine = QvcEngine(model.model_config, sd, device, parallel_branches=args.branches, pack=rank == 0)
+    from quickvc_official_amd import lib as qlib
+    for kv in args.debug:
+        name, _, val = kv.partition("=")
+        qlib.debug_set(name, int(val))
     if world > 1:
         qd.broadcast_blob(engine.blob, src=0)                 # RCCL over xGMI, once
     B = args.batch
@@ -191,7 +198,8 @@ def main() -> None:
                    "operands": {"f16": "f16 MFMA operands, fp32 accumulate", "bf16": "bf16 MFMA operands, fp32 accumulate",
                                 "bf16x": "bf16 MFMA operands in the fused ResBlock pairs (80 % of the FLOPs) with an f16 residual stream, f16 operands elsewhere, fp32 accumulate"}[args.dtype], "hipgraph": graph is not None,
                    "parallel_resblock_branches": False,     # set below from the launch records: only unfused stages fork
-                   "parallelism": f"utterance-sharded x{world}, no per-step collective"},
+                   "parallelism": f"utterance-sharded x{world}, no per-step collective",
+                   **({"debug_switches": args.debug} if args.debug else {})},
         "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
         "steady_state": steady,
     }
@@ -218,10 +226,10 @@ def main() -> None:
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_bench.sh writes
-        # profiles/r02_traffic.json with the hash of the kernel sources it was measured on).  It is reported only
+        # profiles/r03_traffic.json with the hash of the kernel sources it was measured on).  It is reported only
         # when that hash matches the sources of THIS run and the file names the dominant kernel; otherwise null.
         traffic, traffic_source = None, "no PMC file for these kernel sources (run tools/profile_bench.sh)"
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if args.batch != BATCH:
             traffic_source = f"the PMC file is for batch {BATCH} per GPU (bytes per launch scale with the batch)"
         elif os.path.exists(tpath):

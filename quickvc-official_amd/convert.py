@@ -38,9 +38,9 @@ from .frontend import MelFrontend, load_wav, trim
 from .model import SynthesizerTrn
 
 
-def _unit_path(src: str) -> str:
+def _unit_path(src: str, check: bool = True) -> str:
     path = src if src.endswith(".npy") else os.path.splitext(src)[0] + ".npy"
-    if not os.path.exists(path):
+    if check and not os.path.exists(path):
         raise FileNotFoundError(f"no unit file for {src}: HuBERT-soft is not available offline; provide {path} "
                                 "(frames, 256) fp32 as written by the reference's dataset/encode.py")
     return path
@@ -84,8 +84,13 @@ def rank_plan(items, rank: int, world: int, batch: int, pool=None):
     (on ``pool``, a fileio.IoPool, in parallel when given), so every rank can plan the whole corpus while loading only
     its own share."""
     if pool is not None and items:
-        paths = [_unit_path(src) for _, src, _ in items]
-        shapes = pool.npy_shapes(paths)
+        paths = [_unit_path(src, check=False) for _, src, _ in items]     # a missing file fails in the native open, with its error
+        try:
+            shapes = pool.npy_shapes(paths)
+        except Exception:
+            for _, src, _ in items:
+                _unit_path(src)                                           # says WHICH unit file is missing (and why there must be one)
+            raise
         for path, (_f, c) in zip(paths, shapes):
             if c != 256:
                 raise ValueError(f"{path}: expected (frames, 256), got ({_f}, {c})")
@@ -143,7 +148,9 @@ class CorpusPipeline:
         # the host while batch k computes (one stream would serialise 1 GB of PCIe traffic with the kernels)
         self.stream = torch.cuda.Stream(self.dev)
         self.up_stream, self.down_stream = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
-        self.stats = {"utterances": 0, "samples": 0, "batches": 0}
+        # where the threads spend their time (seconds): *_wait = blocked on the neighbouring stage
+        self.stats = {"utterances": 0, "samples": 0, "batches": 0, "load_s": 0.0, "load_wait_s": 0.0, "enqueue_s": 0.0,
+                      "enqueue_wait_s": 0.0, "write_s": 0.0, "write_wait_s": 0.0, "gpu_wait_s": 0.0, "embed_s": 0.0}
 
     def close(self) -> None:
         self.load_pool.close()
@@ -162,7 +169,10 @@ class CorpusPipeline:
         def loader():
             try:
                 for idxs in batches:
+                    tw = time.perf_counter()
                     s = free_q.get()
+                    tl = time.perf_counter()
+                    self.stats["load_wait_s"] += tl - tw
                     n, tmax = len(idxs), max(int(lengths[i]) for i in idxs)
                     if n > self.batch or tmax > self.max_frames:
                         raise ValueError(f"batch of {n} x {tmax} frames exceeds the pipeline's buffers ({self.batch} x {self.max_frames})")
@@ -170,6 +180,7 @@ class CorpusPipeline:
                     self.load_pool.load_units([src_paths[i] for i in idxs], dst, s["lens_pin"])
                     if [int(v) for v in s["lens_pin"][:n]] != [int(lengths[i]) for i in idxs]:
                         raise ValueError("a unit file changed its length since the run was planned")
+                    self.stats["load_s"] += time.perf_counter() - tl
                     ready_q.put((s, idxs, n, tmax))
             except Exception as exc:                          # noqa: BLE001 -- reported by run()
                 errors.append(exc)
@@ -179,14 +190,21 @@ class CorpusPipeline:
         def writer():
             try:
                 while True:
+                    tw = time.perf_counter()
                     item = done_q.get()
                     if item is None:
                         return
                     s, idxs, n, tmax = item
+                    tg = time.perf_counter()
                     s["done"].synchronize()
+                    t0w = time.perf_counter()
                     out = s["out_pin"][:n * tmax * self.spf].view(n, tmax * self.spf)
                     self.write_pool.write_wavs([out_paths[i] for i in idxs], out, [int(lengths[i]) * self.spf for i in idxs], self.rate)
                     free_q.put(s)
+                    t1w = time.perf_counter()
+                    self.stats["write_wait_s"] += tg - tw
+                    self.stats["gpu_wait_s"] += t0w - tg
+                    self.stats["write_s"] += t1w - t0w
             except Exception as exc:                          # noqa: BLE001
                 errors.append(exc)
                 while done_q.get() is not None:               # drain so that the main thread never blocks on us
@@ -195,7 +213,10 @@ class CorpusPipeline:
         lt, wt = threading.Thread(target=loader, daemon=True), threading.Thread(target=writer, daemon=True)
         lt.start(); wt.start()
         if callable(g_rows):
+            te = time.perf_counter()
             g_rows = g_rows()
+            torch.cuda.synchronize(self.dev)
+            self.stats["embed_s"] = time.perf_counter() - te
         # every batch's item indices on the device up front: a per-batch host -> device copy of a Python list is a
         # SYNCHRONOUS copy on the compute stream -- it made the host wait for the previous batch's kernels before it could
         # enqueue the next ones (2.75 ms per batch against 2.2 ms of kernels)
@@ -210,7 +231,10 @@ class CorpusPipeline:
         try:
             with torch.no_grad(), torch.cuda.stream(self.stream):
                 while True:
+                    tw = time.perf_counter()
                     item = ready_q.get()
+                    te = time.perf_counter()
+                    self.stats["enqueue_wait_s"] += te - tw
                     if item is None or errors:
                         break
                     s, idxs, n, tmax = item
@@ -232,6 +256,7 @@ class CorpusPipeline:
                         s["out_pin"][:n * tmax * self.spf].copy_(out.view(-1), non_blocking=True)
                         s["done"].record(self.down_stream)
                     done_q.put(item)
+                    self.stats["enqueue_s"] += time.perf_counter() - te
                     self.stats["utterances"] += n
                     self.stats["samples"] += sum(int(lengths[i]) for i in idxs) * self.spf
                     self.stats["batches"] += 1
@@ -319,18 +344,37 @@ def convert_items(net_g, d, items, outdir: str, rank: int = 0, world: int = 1, b
         stamp = time.strftime('%m-%d_%H-%M', time.localtime())
         out_paths = [os.path.join(outdir, f"{stamp}_{t}.wav" if use_timestamp else f"{t}.wav") for t, _, _ in items]
         mine_set = set(mine)
-        src_paths = [_unit_path(src) if i in mine_set else None for i, (_, src, _) in enumerate(items)]
-        pipe = CorpusPipeline(net_g, min(batch, max(len(b) for b in batches)), max(lengths[i] for i in mine), d.sampling_rate,
-                              io_threads=io_threads, seed=seed)
+        src_paths = [_unit_path(src, check=False) if i in mine_set else None for i, (_, src, _) in enumerate(items)]
+        # the pipeline's buffers (pinned host memory, workspace, I/O pools: tens of ms) are set up on a helper thread
+        # while this one embeds the target speakers
+        net_g.engine()                                                    # packed once, before two threads ask for it
+        box = {}
+
+        def make_pipe():
+            try:
+                with torch.cuda.device(dev_index):
+                    box["pipe"] = CorpusPipeline(net_g, min(batch, max(len(b) for b in batches)), max(lengths[i] for i in mine),
+                                                 d.sampling_rate, io_threads=io_threads, seed=seed)
+            except Exception as exc:                                      # noqa: BLE001 -- re-raised below
+                box["error"] = exc
+
+        dev_index = torch.cuda.current_device()
+        th = threading.Thread(target=make_pipe, daemon=True)
+        th.start()
+        g_rows = embed_targets()
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        pipe = box["pipe"]
         try:
             t2 = time.perf_counter()
-            pipe.run(batches, src_paths, out_paths, lengths, embed_targets)   # the targets are embedded while the loader fills the first slots
+            pipe.run(batches, src_paths, out_paths, lengths, g_rows)
             torch.cuda.synchronize()
             t3 = time.perf_counter()
         finally:
             pipe.close()
     if timings is not None:
-        timings.update(plan_s=t1 - t0, setup_s=t2 - t1, pipeline_s=t3 - t2, targets=n_targets[0])
+        timings.update(plan_s=t1 - t0, setup_and_embed_s=t2 - t1, pipeline_s=t3 - t2, targets=n_targets[0])
     return pipe.stats
 
 

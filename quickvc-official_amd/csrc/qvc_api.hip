@@ -153,7 +153,7 @@ struct TimedBackend {
     for (int i = 0; i < a.n; ++i) {
       const double outs = (double)batch * a.p[i].T * a.p[i].C;
       fl += 2.0 * 2.0 * outs * a.p[i].C * a.p[i].k;
-      by += outs * 2 * 3 + (double)d1[i].w_bytes() + (double)d2[i].w_bytes();
+      by += outs * 2 * 2 + (double)d1[i].w_bytes() + (double)d2[i].w_bytes();   // algorithmic: the stream read once, written once (the kernel's second read of x for the residual is NOT counted: it shows up as traffic / algorithmic > 1)
     }
     note(name, fl, by);
     return st;

@@ -1263,6 +1263,10 @@ inline TileChoice choose_tile(const ConvDesc& d, int Nq, int batch, const int* n
     if (NF != QVC_FORCE_NF) continue;                           // developer sweep (tools/conv_bench)
 #endif
     if (d.MF * NF * 4 > 160) continue;                          // accumulator registers
+    // polyphase up-samplers have s * Cout rows = many row chunks, and every workgroup streams its chunk's whole K:
+    // with 32-frame tiles up-sampler 0 pulls 4.9 MB of weights into every CU (45 us at the ~50 B/clk a CU takes in) --
+    // 64-frame tiles halve that while the launch still has two workgroups per CU (57.9 -> 50.3 us, bit-identical)
+    if (d.up_s > 1 && NF < 4 && (long)ceil_div(Nq, WN * 4 * 16) * batch * d.nchunk >= 512) continue;
     const int NT = WN * NF * 16;
     const size_t lds = (size_t)(NT + halo) * rowbytes;
     if (lds > 160 * 1024) continue;

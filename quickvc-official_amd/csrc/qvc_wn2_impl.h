@@ -9,7 +9,7 @@
 // phase boundary (gate math, barriers, epilogue, the next GEMM's ring priming) and spend ~45 instructions per k-step
 // on addresses and loop control.  Here
 //   * the launch's weights are ONE stream per wave -- layer l's k-tap conv, its 1x1, layer l+1's conv ... -- prefetched
-//     FIVE k-steps ahead through a six-slot register ring that never drains: while a wave does its gate math, waits at
+//     SIX k-steps ahead through a six-slot register ring that never drains (a slot is refilled right after its MFMAs): while a wave does its gate math, waits at
 //     a barrier or runs an epilogue, the next GEMM's fragments are already on their way;
 //   * a layer's 36 k-steps are fully unrolled for the shipped shape (hidden 192, kernel 5): ring slots, taps and LDS
 //     offsets are compile-time constants, the B-fragment address of a k-step is one of ten per-lane bases computed once
@@ -28,6 +28,15 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Developer experiment (tools/conv_bench): re-synchronise the workgroup's waves every QVC_WN2_SYNC k-steps of GEMM1.
+// The three waves of a SIMD do not advance together -- the oldest wins every arbitration and finishes its k-tap GEMM
+// in 6 k cycles, the youngest needs 14 k -- and the idea was that a wave idling at the layer's barrier streams nothing.
+// Measured (profiles/r03_wn_stamps.txt): with a plain s_barrier every 6 k-steps ALL waves take 14.2 k cycles and the
+// layer gets slower (12.8 vs 12.2 us): the CU's intake of ~50 B/clk is the bound whoever issues the loads.  Off.
+#ifndef QVC_WN2_SYNC
+#define QVC_WN2_SYNC 0
+#endif
+
 // the shapes this kernel is built for
 inline bool wn2_supported(const ConvDesc& din, const WnStackArgs& a) {
   return wn_layout_ok(din) && din.CinP == 192 && din.taps == 5 && a.layers >= 1 && a.layers <= 4 && wn_stack_nf(din.taps, a.layers) == 3 &&
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
   constexpr int NF = 3, NB = NF * 16, OUTF = kWnOutFrames, ON = 3;
   constexpr int LEFT = (TAPS - 1) / 2, R = NB + TAPS - 1;
   constexpr int NK1 = TAPS * KS, NK2 = KS, NKL = NK1 + NK2;
-  constexpr int RING = 6, PF = RING - 1;
+  constexpr int RING = 6, PF = RING;          // a k-step's slot is refilled right after its MFMAs: six k-steps (12 KiB per wave) in flight
   static_assert(NKL % RING == 0, "a layer must start on ring slot 0");
   static_assert(CPR % 8 == 0 && CPR % 16 != 0, "row swizzle = row & 7 (see swz_mode)");
   constexpr int ACTS = R * RB;                // byte offset of the gated-activation tile
@@ -71,7 +80,10 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
   const int w0 = q0 - halo;                   // first frame of the window; column j <-> frame w0 + j
   char* acts = smem + ACTS;
 
+  const int ch0 = wm * 16 + lq * 4;           // this lane's four channels
   // ---- the weight stream: request the first PF k-steps of layer 0 before anything else
+  // (issuing the prologue's own few loads -- x, the running skip sum -- ahead of the ring was tried: the prologue got
+  //  longer, 8.9 k -> 10.7 k cycles, profiles/r03_wn_stamps.txt)
   frag ring[RING][2];
   const frag* ap1 = static_cast<const frag*>(a.w_in[0]) + ((size_t)wm * NK1 * 2) * 64 + lane;
 #pragma unroll
@@ -95,7 +107,6 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
   // zero the x tile once: rows outside the window and K-padding channels must stay finite zeros
   for (int i = tid; i < (R * RB) >> 4; i += NTH) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-  const int ch0 = wm * 16 + lq * 4;           // this lane's four channels
   f32x4 xr[NF];
   if (a.w_pre) {
     // fused `pre` 1x1 (modules.py:212): the z slice of the window through the (still unused) acts tile
@@ -209,7 +220,6 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
       read_b(std::integral_constant<int, 0>{}, bf[0]);
       auto step = [&](auto k_c) {
         constexpr int k = decltype(k_c)::value;
-        if (!QVC_ABL(5)) prefetch(std::integral_constant<int, k + PF>{});
         if constexpr (k + 1 < NK1) { if (!QVC_ABL(6)) read_b(std::integral_constant<int, k + 1>{}, bf[(k + 1) & 1]); }
         if constexpr (k == NK1 - 6) { bt = *reinterpret_cast<const float4*>(bb); bs = *reinterpret_cast<const float4*>(bb + a.H); }
         __builtin_amdgcn_sched_barrier(0);
@@ -218,6 +228,8 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
 #pragma unroll
           for (int m = 0; m < 2; ++m) acc[m][n] = O::mfma(ring[k % RING][m], bf[k & 1][n], acc[m][n]);
         __builtin_amdgcn_sched_barrier(0);
+        if (!QVC_ABL(5)) prefetch(std::integral_constant<int, k + PF>{});      // into the slot these MFMAs have just read
+        if constexpr (QVC_WN2_SYNC > 0 && (k + 1) % (QVC_WN2_SYNC > 0 ? QVC_WN2_SYNC : 1) == 0 && k + 1 < NK1) __builtin_amdgcn_s_barrier();
       };
       static_for<NK1>(step);
 #ifdef QVC_STAMP
@@ -240,12 +252,11 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
       }
     }
     // res / skip biases: requested before the barrier, used after GEMM2
-    const float* brs = a.b_rs[l];
-    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-    if (ch0 < a.H) {
-      b0 = *reinterpret_cast<const float4*>(brs + ch0);
-      if (!last) b1 = *reinterpret_cast<const float4*>(brs + a.H + ch0);
-    }
+    // (unconditional loads from clamped addresses: a branch around a load makes the compiler's wait counts assume the path
+    //  without it, and GEMM2's k-steps then wait for the prefetches issued one step earlier)
+    const float* brs = a.b_rs[l] + (ch0 < a.H ? ch0 : 0);
+    const float4 b0 = *reinterpret_cast<const float4*>(brs);
+    const float4 b1 = *reinterpret_cast<const float4*>(brs + (last ? 0 : a.H));
 #ifdef QVC_STAMP
     if (l < 4) QVC_ST(3 + 6 * l);
 #endif
@@ -269,7 +280,6 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
       read_b(std::integral_constant<int, 0>{}, bf[0]);
       auto step = [&](auto k_c) {
         constexpr int k = decltype(k_c)::value;       // k-step of GEMM2; stream position NK1 + k
-        if (!QVC_ABL(5)) prefetch(std::integral_constant<int, NK1 + k + PF>{});
         if constexpr (k + 1 < NK2) { if (!QVC_ABL(6)) read_b(std::integral_constant<int, k + 1>{}, bf[(k + 1) & 1]); }
         __builtin_amdgcn_sched_barrier(0);
         if (!last) {
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
           for (int n = 0; n < NF; ++n) acc[0][n] = O::mfma(ring[(NK1 + k) % RING][0], bf[k & 1][n], acc[0][n]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!QVC_ABL(5)) prefetch(std::integral_constant<int, NK1 + k + PF>{});
       };
       static_for<NK2>(step);
 #ifdef QVC_STAMP

@@ -1104,6 +1104,31 @@ def test_convert_cli_corpus_pipeline(lib, dev, tmp_path):
     assert torch.equal(a_cm, a_fm)
 
 
+def test_bench_starts_its_own_workers(lib, dev):
+    """`python bench.py --gpus 2` with no launcher around it must start its two ranks itself (fresh processes, before any
+    GPU call in the parent), have rank 0 pack and broadcast the blob, and print ONE JSON line for the whole job.
+    On this one-GPU box the ranks share cuda:0 and talk over gloo (--rehearsal); the driver's 2 / 4 / 8-GPU runs take
+    the same code with one GPU per rank and RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                          "--rehearsal", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["batch_per_gpu"] == 4 and "roofline" in out
+    # a failing worker must fail the parent: --gpus 2 with an impossible batch
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "0",
+                          "--rehearsal", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
+
+
 def test_convert_cli_two_ranks_rehearsal(lib, dev, tmp_path):
     """BASELINE configs[3] control flow on a one-GPU box: the CLI started as TWO ranks (RANK / WORLD_SIZE as
     torch.distributed.run sets them; ``--device 0`` puts both on cuda:0).  Each rank plans from the .npy headers,

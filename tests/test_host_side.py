@@ -68,6 +68,55 @@ def test_no_hot_kernel_spills_to_scratch(built):
     assert seen == set(hot), set(hot) - seen
 
 
+def test_io_library_exports_and_matches_numpy_and_scipy(built, tmp_path):
+    """libqvc_io.so (include/qvc_io.h): every declared symbol is exported; unit files written by np.save (the reference's
+    on-disk format, dataset/encode.py:38 -- format 1.0 and 2.0 headers) come back bit for bit in the frame-major batch
+    layout; wav files are byte-identical to scipy.io.wavfile.write as convert.py:84-86 calls it; bad inputs give the
+    documented error codes instead of raising from native code."""
+    import numpy as np
+    from scipy.io import wavfile
+    from quickvc_official_amd import fileio
+    lib = fileio.load_library()
+    header = open(os.path.join(ROOT, "include", "qvc_io.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(qvc_io_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 6
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/qvc_io.h but not exported"
+    rng = np.random.RandomState(0)
+    arrs = [rng.randn(n, 256).astype(np.float32) for n in (40, 7, 123, 1)]
+    paths = [str(tmp_path / f"u{i}.npy") for i in range(4)]
+    for p, a in zip(paths, arrs):
+        np.save(p, a)
+    with open(paths[3], "wb") as f:                                     # a format-2.0 header (4-byte header length)
+        np.lib.format.write_array(f, arrs[3], version=(2, 0))
+    assert [fileio.npy_shape(p) for p in paths] == [(40, 256), (7, 256), (123, 256), (1, 256)]
+    pool = fileio.IoPool(3)
+    assert pool.npy_shapes(paths) == [(40, 256), (7, 256), (123, 256), (1, 256)]
+    dst = torch.full((4, 123, 256), -7.0)
+    lens = torch.zeros(4, dtype=torch.int32)
+    pool.load_units(paths, dst, lens)
+    assert lens.tolist() == [40, 7, 123, 1]
+    for i, a in enumerate(arrs):
+        assert np.array_equal(dst[i, :len(a)].numpy(), a)
+    assert float(dst[1, 7:].max()) == -7.0                              # rows past an utterance's end are left alone
+    src = torch.from_numpy(rng.randn(3, 5000).astype(np.float32))
+    outs = [str(tmp_path / f"o{i}.wav") for i in range(3)]
+    pool.write_wavs(outs, src, [5000, 320, 0], 16000)
+    for i, n in enumerate((5000, 320, 0)):
+        ref = str(tmp_path / f"r{i}.wav")
+        wavfile.write(ref, 16000, src[i, :n].numpy())
+        assert open(ref, "rb").read() == open(outs[i], "rb").read()
+    with pytest.raises(fileio.QvcIoError, match="more frames than the slot"):
+        pool.load_units(paths, torch.zeros(4, 50, 256), lens)
+    np.save(str(tmp_path / "f64.npy"), np.zeros((3, 256)))
+    with pytest.raises(fileio.QvcIoError, match="float32"):
+        fileio.npy_shape(str(tmp_path / "f64.npy"))
+    with pytest.raises(fileio.QvcIoError, match="opened"):
+        fileio.npy_shape(str(tmp_path / "missing.npy"))
+    pool.close()
+
+
 def test_package_fails_loudly_without_gpu_or_library(built, monkeypatch):
     import quickvc_official_amd as q
     from quickvc_official_amd import lib as L

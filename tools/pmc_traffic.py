@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r02_traffic.json.
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r03_traffic.json.
 
 HBM bytes per launch, per kernel, as MI355X_MICROARCH.md (HBM section) prescribes: separate passes for
 FETCH_SIZE and WRITE_SIZE, both in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
 reads, so it is doubled; WRITE_SIZE is taken as is.  (Narrower access widths are uncalibrated.)
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r03_traffic.json
 """
 import collections
 import csv
@@ -29,9 +29,13 @@ EPI = {'1': 'gau', '3': 'smp'}   # EpiKind (qvc_plan.h)
 
 
 def pretty(name):
-    m = re.search(r"rbpair_persist_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)E", name)
+    m = re.search(r"rbchain_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E(DF16_)?", name)
     if m:
-        return f"rbpair_persist<{'f16' if m.group(1) == 'DF16_' else 'bf16'},MF{m.group(2)},NF{m.group(3)}>"
+        t = "f16" if m.group(1) == "DF16_" else ("bf16x" if m.group(5) else "bf16")
+        return f"rbchain<{t},MF{m.group(2)},NF{m.group(3)},WM{m.group(4)}>"
+    m = re.search(r"wn_stack2_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", name)
+    if m:
+        return f"wn_stack2<{'f16' if m.group(1) == 'DF16_' else 'bf16'},W{2 * int(m.group(2))},L4{',pre+post' if m.group(4) != '0' else ''}>"
     m = re.search(r"rbpair_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi\d+E(DF16_)?", name)
     if m:   # 6th template argument = stream type: spelled out (DF16_) only when it differs from the operand type
         t = "f16" if m.group(1) == "DF16_" else ("bf16x" if m.group(5) else "bf16")

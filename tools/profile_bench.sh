@@ -2,14 +2,14 @@
 # Round profile (run on the GPU box): the bench line, rocprofv3 kernel stats of the same command, HBM-traffic PMC
 # passes (FETCH_SIZE / WRITE_SIZE, separate) and SQ / TCP counter passes of the real step (eager launches).
 # Outputs land under gpurun_out/; copy the summaries into profiles/ afterwards:
-#   r02_bench.json, prof_r02/r02_kernel_stats.csv, r02_traffic.json, r02_sq_counters.json
+#   r03_bench.json, prof_r03/r03_kernel_stats.csv, r03_traffic.json, r03_sq_counters.json
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 rm -rf gpurun_out/prof_$R gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq_a gpurun_out/pmc_sq_b gpurun_out/pmc_sq_c gpurun_out/pmc_sq_e
-python bench.py --steps 20 --warmup 3 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err || exit 1
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err || exit 1
 echo "bench done"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o $R --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${R}_bench_prof.json 2> gpurun_out/prof.err || exit 2
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o $R --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${R}_bench_prof.json 2> gpurun_out/prof.err || exit 2
 echo "kernel stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > /dev/null 2> gpurun_out/pmc_fetch.err || exit 3
 echo "fetch done"
