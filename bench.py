@@ -82,6 +82,10 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16x", choices=["f16", "bf16", "bf16x"],
                     help="MFMA operand mode: bf16x (default) = bf16 operands in the ResBlock pairs (80 %% of the FLOPs) with f16 residual "
                          "streams, f16 elsewhere: BASELINE.json names bf16 and >= 40 dB; all-bf16 measures 34 dB, bf16x 45.6 dB, f16 52 dB")
+    ap.add_argument("--in-flight", type=int, default=2, metavar="N",
+                    help="batches in flight per GPU: step i runs on lane i %% N, each lane with its own inputs, workspace, output, "
+                         "hipGraph and HIP stream, so the next batch fills the launch tails and dependency gaps of the current "
+                         "one (results are bit-identical to one lane; 1 = strictly one batch at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches (only stages whose pairs do NOT run fused take that path)")
@@ -131,56 +135,83 @@ def main() -> None:
     if world > 1:
         qd.broadcast_blob(engine.blob, src=0)                 # RCCL over xGMI, once
     B = args.batch
-    unit, g, noise = make_synthetic_inputs(B, FRAMES, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=rank * B)
-    unit, g, noise = unit.to(device), g.to(device), noise.to(device)
-    out = torch.empty(B, 1, FRAMES * engine.samples_per_frame, dtype=torch.float32, device=device)
+    n_lanes = max(1, args.in_flight)
 
-    # ---- one step, optionally as a hipGraph (the library call is capturable: no sync/alloc inside)
-    stream = torch.cuda.Stream(device)
-    graph = None
-    ws = engine.alloc_workspace(B, FRAMES)                   # the graph bakes its pointer in: owned here, not shared
-    with torch.cuda.stream(stream):
-        engine.infer_batch(unit, g, noise, out, ws=ws)       # loads code objects
-        stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                engine.infer_batch(unit, g, noise, out, ws=ws)
+    # ---- one step = one batch through the hot path, optionally as a hipGraph (the library call is capturable: no
+    #      sync/alloc inside).  A lane owns everything a batch touches -- inputs, workspace (the graph bakes its pointer
+    #      in), output, graph, stream -- so consecutive steps on different lanes are independent and may overlap.
+    lanes = []
+    for k in range(n_lanes):
+        u_k, g_k, n_k = make_synthetic_inputs(B, FRAMES, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=(rank + world * k) * B)
+        lane = {"unit": u_k.to(device), "g": g_k.to(device), "noise": n_k.to(device), "stream": torch.cuda.Stream(device), "graph": None,
+                "out": torch.empty(B, 1, FRAMES * engine.samples_per_frame, dtype=torch.float32, device=device),
+                "ws": engine.alloc_workspace(B, FRAMES)}
+        with torch.cuda.stream(lane["stream"]):
+            engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])       # loads code objects
+            lane["stream"].synchronize()
+            if not args.no_graph:
+                lane["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(lane["graph"], stream=lane["stream"]):
+                    engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])
+        lanes.append(lane)
+    unit, g, noise, out, stream, graph = (lanes[0][k] for k in ("unit", "g", "noise", "out", "stream", "graph"))
+    step_no = [0]
 
-    def step():
-        if graph is not None:
-            graph.replay()
-        else:
-            engine.infer_batch(unit, g, noise, out, ws=ws)
+    def step(in_flight=n_lanes):
+        lane = lanes[step_no[0] % in_flight]
+        step_no[0] += 1
+        with torch.cuda.stream(lane["stream"]):
+            if lane["graph"] is not None:
+                lane["graph"].replay()
+            else:
+                engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    # The device needs ~20 steps (~45 ms) after idle to reach its steady clock (tools/warmup_probe.py: 2.24, 2.50,
+    # 2.35, 2.25, 2.16 ... -> 1.98 ms per step), so with a handful of warm-up steps `value` above still contains
+    # part of that ramp.  A second window of K steps, 40 steps later, is reported next to it as `steady_state`.
+    for _ in range(40):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    wall_steady = time.perf_counter() - t1
+    # strictly one batch at a time, for comparison (and what the per-kernel profile under profiles/ is taken on)
+    wall_single = wall_steady
+    lanes_identical = True
+    if n_lanes > 1:
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t2 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step(1)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        # The device needs ~20 steps (~45 ms) after idle to reach its steady clock (tools/warmup_probe.py: 2.24, 2.50,
-        # 2.35, 2.25, 2.16 ... -> 1.98 ms per step), so with a handful of warm-up steps `value` above still contains
-        # part of that ramp.  A second window of K steps, 40 steps later, is reported next to it as `steady_state`.
-        for _ in range(40):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        wall_steady = time.perf_counter() - t1
+        wall_single = time.perf_counter() - t2
+        # overlap must not change a single bit: every lane's output against the same graph run alone
+        for lane in lanes:
+            before = lane["out"].clone()
+            with torch.cuda.stream(lane["stream"]):
+                (lane["graph"].replay() if lane["graph"] is not None else
+                 engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"]))
+            torch.cuda.synchronize()
+            lanes_identical = lanes_identical and bool(torch.equal(before, lane["out"]))
     wall = qd.max_over_ranks(wall, device)
     wall_steady = qd.max_over_ranks(wall_steady, device)
+    wall_single = qd.max_over_ranks(wall_single, device)
     samples_per_step = world * B * FRAMES * engine.samples_per_frame
     value = samples_per_step * args.steps / wall
     ms_per_step = wall / args.steps * 1e3
@@ -199,9 +230,14 @@ def main() -> None:
                                 "bf16x": "bf16 MFMA operands in the fused ResBlock pairs (80 % of the FLOPs) with an f16 residual stream, f16 operands elsewhere, fp32 accumulate"}[args.dtype], "hipgraph": graph is not None,
                    "parallel_resblock_branches": False,     # set below from the launch records: only unfused stages fork
                    "parallelism": f"utterance-sharded x{world}, no per-step collective",
+                   "batches_in_flight": n_lanes,
                    **({"debug_switches": args.debug} if args.debug else {})},
         "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
         "steady_state": steady,
+        "one_batch_at_a_time": {"ms_per_step": wall_single / args.steps * 1e3, "value": samples_per_step * args.steps / wall_single,
+                                "note": "the same graphs replayed on one lane only (steady clock); the per-launch durations of the "
+                                        "roofline leg and of the rocprofv3 summary are taken in this mode",
+                                "lanes_bit_identical_to_running_alone": lanes_identical},
     }
 
     if rank == 0:

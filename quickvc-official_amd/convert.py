@@ -116,12 +116,15 @@ class CorpusPipeline:
 
     ``slots`` buffer sets rotate through three stages that run concurrently:
       load   (loader thread + native I/O pool): unit files -> pinned (B, Tmax, 256) fp32, frame-major as on disk;
-      convert (caller's thread, side stream):   async upload, qvc_infer_batch_ragged_fm, async download into pinned memory;
+      convert (caller's thread, side streams):  async upload, qvc_infer_batch_ragged_fm, async download into pinned memory;
       write  (writer thread + native I/O pool): float32 wav files, byte-identical to scipy.io.wavfile.write.
+    ``lanes`` batches are converted at the same time, each on a compute stream and workspace of its own: the kernels of
+    batch k+1 fill the launch tails and dependency gaps of batch k (about -6 % per batch at 32 x 5 s, bench.py
+    --in-flight); the results do not depend on it.
     """
 
-    def __init__(self, net_g, batch: int, max_frames: int, sampling_rate: int, slots: int = 3, io_threads: int = 8,
-                 seed: int = 0):
+    def __init__(self, net_g, batch: int, max_frames: int, sampling_rate: int, slots: int = 4, io_threads: int = 8,
+                 seed: int = 0, lanes: int = 2):
         from .fileio import IoPool
         self.net_g, self.engine = net_g, net_g.engine()
         self.dev = self.engine.device
@@ -132,7 +135,8 @@ class CorpusPipeline:
         self.load_pool, self.write_pool = IoPool(io_threads), IoPool(io_threads)
         B, Tm = self.batch, self.max_frames
         self.slots = []
-        for _ in range(max(2, int(slots))):
+        self.lanes = max(1, int(lanes))
+        for _ in range(max(self.lanes + 1, int(slots))):
             self.slots.append(dict(
                 unit_pin=torch.empty(B * Tm * self.uc, dtype=torch.float32).pin_memory(),
                 lens_pin=torch.empty(B, dtype=torch.int32).pin_memory(),
@@ -143,10 +147,10 @@ class CorpusPipeline:
                 done=torch.cuda.Event()))
         for s in self.slots:
             s["up"], s["comp"] = torch.cuda.Event(), torch.cuda.Event()
-        self.ws = self.engine.alloc_workspace(B, Tm)
+        self.ws = [self.engine.alloc_workspace(B, Tm) for _ in range(self.lanes)]
         # uploads, kernels and downloads on streams of their own: batch k+1 travels to the GPU and batch k-1 back to
         # the host while batch k computes (one stream would serialise 1 GB of PCIe traffic with the kernels)
-        self.stream = torch.cuda.Stream(self.dev)
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.lanes)]
         self.up_stream, self.down_stream = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         # where the threads spend their time (seconds): *_wait = blocked on the neighbouring stage
         self.stats = {"utterances": 0, "samples": 0, "batches": 0, "load_s": 0.0, "load_wait_s": 0.0, "enqueue_s": 0.0,
@@ -227,9 +231,10 @@ class CorpusPipeline:
             offs.append(o)
             o += len(idxs)
         bi = 0
-        self.stream.wait_stream(torch.cuda.current_stream(self.dev))     # g_rows may still be pending there
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream(self.dev))          # g_rows may still be pending there
         try:
-            with torch.no_grad(), torch.cuda.stream(self.stream):
+            with torch.no_grad():
                 while True:
                     tw = time.perf_counter()
                     item = ready_q.get()
@@ -244,13 +249,17 @@ class CorpusPipeline:
                         unit.copy_(s["unit_pin"][:n * tmax * self.uc].view(n, tmax, self.uc), non_blocking=True)
                         lens.copy_(s["lens_pin"][:n], non_blocking=True)
                         s["up"].record(self.up_stream)
-                    noise = batch_noise(self.seed, idxs[0], n, self.inter, tmax, self.dev)
-                    g = g_rows.index_select(0, idx_dev[offs[bi]:offs[bi] + n])
+                    lane = bi % self.lanes                    # a stream's order keeps a lane's workspace to one batch at a time
+                    stream = self.streams[lane]
+                    with torch.cuda.stream(stream):
+                        noise = batch_noise(self.seed, idxs[0], n, self.inter, tmax, self.dev)
+                        g = g_rows.index_select(0, idx_dev[offs[bi]:offs[bi] + n])
+                        out = s["out_dev"][:n * tmax * self.spf].view(n, 1, tmax * self.spf)
+                        stream.wait_event(s["up"])
+                        self.engine.infer_batch_ragged(unit, g, noise, lens, out=out, ws=self.ws[lane], unit_fm=True)
+                        s["comp"].record(stream)
+                        # the caching allocator hands noise / g back to THIS stream's pool once they go out of scope
                     bi += 1
-                    out = s["out_dev"][:n * tmax * self.spf].view(n, 1, tmax * self.spf)
-                    self.stream.wait_event(s["up"])
-                    self.engine.infer_batch_ragged(unit, g, noise, lens, out=out, ws=self.ws, unit_fm=True)
-                    s["comp"].record(self.stream)
                     with torch.cuda.stream(self.down_stream):
                         self.down_stream.wait_event(s["comp"])
                         s["out_pin"][:n * tmax * self.spf].copy_(out.view(-1), non_blocking=True)
@@ -281,6 +290,7 @@ def main(argv=None) -> None:
     p.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x"])
     p.add_argument("--device", type=int, default=None, help="GPU ordinal (default: LOCAL_RANK); rehearsals of several ranks on one GPU pass 0")
     p.add_argument("--io-threads", type=int, default=8, help="native I/O worker threads per direction")
+    p.add_argument("--lanes", type=int, default=2, help="batches converted at the same time (compute streams); the output does not depend on it")
     args = p.parse_args(argv)
 
     os.makedirs(args.outdir, exist_ok=True)
@@ -303,11 +313,12 @@ def main(argv=None) -> None:
     seed = args.seed if args.seed is not None else int.from_bytes(os.urandom(4), "little")
 
     print("Synthesizing...")
-    convert_items(net_g, hps.data, items, args.outdir, rank, world, args.batch, seed, args.use_timestamp, args.io_threads)
+    convert_items(net_g, hps.data, items, args.outdir, rank, world, args.batch, seed, args.use_timestamp, args.io_threads,
+                  lanes=args.lanes)
 
 
 def convert_items(net_g, d, items, outdir: str, rank: int = 0, world: int = 1, batch: int = 32, seed: int = 0,
-                  use_timestamp: bool = False, io_threads: int = 8, timings: dict = None):
+                  use_timestamp: bool = False, io_threads: int = 8, timings: dict = None, lanes: int = 2):
     """Convert this rank's shard of ``items`` = [(title, src, tgt)] into ``outdir`` (the body of convert.py:58-86)."""
     from .fileio import IoPool
     t0 = time.perf_counter()
@@ -354,7 +365,7 @@ def convert_items(net_g, d, items, outdir: str, rank: int = 0, world: int = 1, b
             try:
                 with torch.cuda.device(dev_index):
                     box["pipe"] = CorpusPipeline(net_g, min(batch, max(len(b) for b in batches)), max(lengths[i] for i in mine),
-                                                 d.sampling_rate, io_threads=io_threads, seed=seed)
+                                                 d.sampling_rate, io_threads=io_threads, seed=seed, lanes=lanes)
             except Exception as exc:                                      # noqa: BLE001 -- re-raised below
                 box["error"] = exc
 

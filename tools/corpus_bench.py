@@ -33,6 +33,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16x", choices=["f16", "bf16", "bf16x"])
     ap.add_argument("--io-threads", type=int, default=8)
+    ap.add_argument("--lanes", type=int, default=2, help="batches converted at the same time in the pipeline")
     ap.add_argument("--scratch", default=None, help="parent of the scratch directory (default: the system temp dir)")
     ap.add_argument("--repeat", type=int, default=2, help="end-to-end passes; the last one is reported (the first warms the page cache)")
     args = ap.parse_args()
@@ -75,7 +76,7 @@ def main() -> None:
             timings = {}
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            stats = cli.convert_items(net_g, d, items, outdir, 0, 1, args.batch, seed=7, io_threads=args.io_threads, timings=timings)
+            stats = cli.convert_items(net_g, d, items, outdir, 0, 1, args.batch, seed=7, io_threads=args.io_threads, timings=timings, lanes=args.lanes)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             e2e.append(dict(wall_s=wall, **timings, stages={k: round(v, 4) for k, v in stats.items() if k.endswith("_s")}))
@@ -122,6 +123,7 @@ def main() -> None:
                            "pipeline_samples_per_s": samples / last["pipeline_s"], "passes": e2e},
             "kernel_only": {"wall_s": kernel_s, "samples_per_s": samples / kernel_s},
             "pipeline_vs_kernel_only": kernel_s / last["pipeline_s"], "end_to_end_vs_kernel_only": kernel_s / last["wall_s"],
+            "lanes": args.lanes,
             "io": {"input_MB": float(lens.sum()) * 1024 / 1e6, "output_MB": samples * 4 / 1e6, "io_threads": args.io_threads,
                    "scratch": os.path.dirname(td), "corpus_generation_s": gen_s},
         }
