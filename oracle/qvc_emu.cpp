@@ -434,8 +434,15 @@ struct EmuBackend {
     return QVC_OK;
   }
   int zero(void* p, size_t bytes) { std::memset(p, 0, bytes); return QVC_OK; }
-  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
-    for (size_t r = 0; r < rows; ++r) std::memmove(static_cast<char*>(dst) + r * dpitch, static_cast<const char*>(src) + r * spitch, width);
+  // csrc/qvc_small.hip copy_batch_kernel: the descriptors of a batch are independent, so their order does not matter
+  int copy_batch(const CopyDesc* d, int n) {
+    if (n < 0 || n > kCopyBatchMax) return QVC_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i)
+      for (size_t r = 0; r < d[i].rows; ++r) {
+        char* dst = static_cast<char*>(d[i].dst) + r * d[i].dpitch;
+        if (d[i].src) std::memcpy(dst, static_cast<const char*>(d[i].src) + r * d[i].spitch, d[i].width);
+        else std::memset(dst, 0, d[i].width);
+      }
     return QVC_OK;
   }
 

@@ -92,9 +92,7 @@ struct HipBackend {
   bool post_tail_ok(const ConvDesc& d) const { return debug_get(DBG_POST_TAIL) != 0 && post_tail_supported(d); }
   int post_tail(const ConvDesc& d, const PostTailArgs& a, int batch, int dtype) { return launch_post_tail(d, a, batch, dtype, stream); }
   int zero(void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH; }
-  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
-    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, stream) == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
-  }
+  int copy_batch(const CopyDesc* d, int n) { return launch_copy_batch(d, n, stream); }
 };
 using Ctx = Path<HipBackend>;
 

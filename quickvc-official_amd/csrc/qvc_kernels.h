@@ -288,6 +288,18 @@ int launch_wn_stack(const ConvDesc& din, const WnStackArgs& a, int batch, int dt
 int wn_stack_variant(const ConvDesc& din, const WnStackArgs& a);   // 2: the continuous-stream kernel (qvc_wn2_impl.h), 1: the generic one
 int launch_wn(const ConvDesc& din, WnArgs a, int batch, int dtype, void* stream, int* nf_out = nullptr);
 int launch_gemv(const GemvArgs& a, void* stream);
+
+// ---- several strided copies / zero fills in ONE launch (the streaming step's ring hand-offs and slides: ~35 strided
+//      memcpys of a few hundred KB each cost ~5 us apiece as separate graph nodes).  All sizes in bytes, multiples of
+//      4; src == nullptr fills with zeros.  The regions written by one batch must not overlap anything the same batch
+//      reads or writes -- the descriptors run concurrently.
+struct CopyDesc {
+  void* dst;
+  const void* src;
+  uint32_t dpitch, spitch, width, rows;
+};
+constexpr int kCopyBatchMax = 12;
+int launch_copy_batch(const CopyDesc* d, int n, void* stream);
 int launch_sample(const SampleArgs& a, void* stream);
 int launch_tail(const TailArgs& a, void* stream);
 int launch_post_tail(const ConvDesc& d, PostTailArgs a, int batch, int dtype, void* stream);

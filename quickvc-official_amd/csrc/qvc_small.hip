@@ -248,6 +248,68 @@ int launch_fm_to_cm(const float* src, float* dst, int batch, int frames, int cha
   return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
 }
 
+// ------------------------------------------------------------------ batched strided copies (qvc_stream.h)
+struct CopyBatchArgs {
+  CopyDesc d[kCopyBatchMax];
+  uint32_t first[kCopyBatchMax + 1];   // first workgroup of descriptor i; first[n] = grid size
+  uint32_t vec[kCopyBatchMax];         // bytes per element: 16 when every address / pitch / width allows it, else 4
+  int32_t n;
+};
+constexpr int kCopyPerThread = 4;      // elements per thread: 16 KiB per workgroup at 16 bytes per element
+
+template <typename V>
+__device__ inline void copy_span(const CopyDesc& d, uint32_t wg) {
+  const uint32_t wv = d.width / (uint32_t)sizeof(V);
+  const uint32_t total = wv * d.rows;
+  const uint32_t e0 = wg * (256u * kCopyPerThread) + threadIdx.x;
+  V v[kCopyPerThread];
+  uint32_t off[kCopyPerThread];
+#pragma unroll
+  for (int k = 0; k < kCopyPerThread; ++k) {
+    const uint32_t e = e0 + (uint32_t)k * 256u;
+    const uint32_t row = e / wv, col = e - row * wv;
+    off[k] = e < total ? row * d.dpitch + col * (uint32_t)sizeof(V) : 0xffffffffu;
+    v[k] = V{};
+    if (e < total && d.src) v[k] = *reinterpret_cast<const V*>(static_cast<const char*>(d.src) + (size_t)row * d.spitch + (size_t)col * sizeof(V));
+  }
+#pragma unroll
+  for (int k = 0; k < kCopyPerThread; ++k)
+    if (off[k] != 0xffffffffu) *reinterpret_cast<V*>(static_cast<char*>(d.dst) + off[k]) = v[k];
+}
+
+__global__ __launch_bounds__(256) void copy_batch_kernel(const CopyBatchArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && blockIdx.x >= a.first[i + 1]) ++i;    // <= 12 descriptors: a scalar scan
+  if (a.vec[i] == 16) copy_span<uint4>(a.d[i], blockIdx.x - a.first[i]);
+  else copy_span<uint32_t>(a.d[i], blockIdx.x - a.first[i]);
+}
+
+int launch_copy_batch(const CopyDesc* d, int n, void* stream) {
+  if (n <= 0) return QVC_OK;
+  if (!d || n > kCopyBatchMax) return QVC_ERR_BAD_ARG;
+  CopyBatchArgs a{};
+  a.n = 0;
+  uint32_t wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    const CopyDesc& c = d[i];
+    if (!c.dst || (c.width | c.dpitch | c.spitch) & 3u || (reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 3u)
+      return QVC_ERR_BAD_ARG;
+    if (c.width == 0 || c.rows == 0) continue;
+    const bool wide = !(((c.width | c.dpitch | c.spitch) & 15u) || ((reinterpret_cast<uintptr_t>(c.dst) | reinterpret_cast<uintptr_t>(c.src)) & 15u));
+    const uint32_t v = wide ? 16u : 4u;
+    const uint64_t total = (uint64_t)(c.width / v) * c.rows;
+    // 32-bit element and destination-offset arithmetic in the kernel
+    if (total >= (1ull << 31) || (uint64_t)c.rows * c.dpitch >= (1ull << 32)) return QVC_ERR_BAD_ARG;
+    a.d[a.n] = c; a.vec[a.n] = v; a.first[a.n] = wgs;
+    wgs += (uint32_t)((total + 256u * kCopyPerThread - 1) / (256u * kCopyPerThread));
+    ++a.n;
+  }
+  if (a.n == 0) return QVC_OK;
+  a.first[a.n] = wgs;
+  hipLaunchKernelGGL(copy_batch_kernel, dim3(wgs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? QVC_OK : QVC_ERR_LAUNCH;
+}
+
 // ------------------------------------------------------------------ conv dispatcher
 int launch_conv(const ConvDesc& d, ConvArgs a, int batch, int epi, int dtype, void* stream, int* nf_out) {
   a.Cin = d.Cin; a.CinP = d.CinP; a.taps = d.taps; a.dil = d.dil; a.left = d.left;

@@ -82,9 +82,10 @@ inline StreamState carve_stream_state(const Plan& P, const StreamGeom& G, int B)
 struct StreamScratch {   // carved from the END of the step's workspace, after the path's own workspace
   int64_t path_bytes = 0;   // workspace of the widest segment
   int64_t noise = 0;        // fp32 (B, C, 2*He + hop): the step's noise placed at the frames enc_p really outputs
-  int64_t zwork = 0;        // fp32 [B][2*Hf + hop][C]: the coupling layer updates z in place on a copy of its ring
+  int64_t zwork[2] = {};    // fp32 [B][2*Hf + hop][C]: the coupling layer updates z in place on a copy of its ring
+                            // (two of them: layer k's result feeds the copy for layer k+1 in the same launch)
   int64_t wave = 0;         // fp32 (B, spf * (2*Hd2 + hop))
-  int64_t tmp = 0;          // slide buffer: the largest ring's kept part
+  int64_t tmp[21] = {};     // slide buffers, one per ring (unit, zf[0..nf), zd, s0[0..3)): that ring's kept part
   int64_t bytes = 0;
 };
 
@@ -97,18 +98,20 @@ inline StreamScratch carve_stream_scratch(const Plan& P, const StreamGeom& G, in
   int64_t off = X.path_bytes;
   auto take = [&](int64_t n) { int64_t o = off; off = align_up(off + n, 256); return o; };
   X.noise = take((int64_t)B * c.inter_channels * (2 * G.He + G.hop) * 4);
-  X.zwork = take((int64_t)B * (2 * G.Hf + G.hop) * c.inter_channels * 4);
+  for (int k = 0; k < 2; ++k) X.zwork[k] = take((int64_t)B * (2 * G.Hf + G.hop) * c.inter_channels * 4);
   X.wave = take((int64_t)B * samples_per_frame(P) * (2 * G.Hd2 + G.hop) * 4);
-  int64_t keep = (int64_t)B * c.unit_channels * 2 * G.He * 4;
-  keep = std::max(keep, (int64_t)B * 2 * G.Hf * c.inter_channels * 4);
-  keep = std::max(keep, (int64_t)B * 2 * G.Hd1 * c.inter_channels * 4);
-  keep = std::max(keep, (int64_t)B * 2 * G.Hd2 * G.r0 * P.stages[0].ch * 2);
-  X.tmp = take(keep);
+  int r = 0;
+  X.tmp[r++] = take((int64_t)B * c.unit_channels * 2 * G.He * 4);
+  for (int k = 0; k < G.nf; ++k) X.tmp[r++] = take((int64_t)B * 2 * G.Hf * c.inter_channels * 4);
+  X.tmp[r++] = take((int64_t)B * 2 * G.Hd1 * c.inter_channels * 4);
+  for (int j = 0; j < 3; ++j) X.tmp[r++] = take((int64_t)B * 2 * G.Hd2 * G.r0 * P.stages[0].ch * 2);
   X.bytes = off;
   return X;
 }
 
-// One step.  Backend adds:  int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows);
+// One step.  Backend adds:  int copy_batch(const CopyDesc* d, int n)  -- n independent strided copies / zero fills in
+// one launch (qvc_kernels.h).  All data movement of a step goes through it: 10 launches where one memcpy per
+// hand-off / slide would be ~35.
 //   unit_new  (B, unit_channels, hop) fp32: unit frames [pos, pos + hop) of every stream
 //   noise_new (B, inter, hop) fp32:         the N(0,1) draw of models.py:94 for frames [pos - He, pos - He + hop)
 //                                           (the frames enc_p finishes in this step)
@@ -127,19 +130,42 @@ int stream_step(const Plan& P, const char* blob, char* state, char* ws, const fl
   const int h = hop, He = G.He, Hf = G.Hf, Hd1 = G.Hd1, Hd2 = G.Hd2;
   int st = QVC_OK;
   auto ok = [&](int rc) { if (st == QVC_OK && rc != QVC_OK) st = rc; };
-  // slide a ring of `rows` rows of (keep + hopb) bytes by hopb bytes (through the scratch: the two parts may overlap)
-  auto slide = [&](char* ring, size_t rows, size_t keep, size_t hopb) {
-    ok(be.copy2d(ws + X.tmp, keep, ring + hopb, keep + hopb, keep, rows));
-    ok(be.copy2d(ring, keep + hopb, ws + X.tmp, keep, keep, rows));
+  CopyDesc cd[kCopyBatchMax];
+  int ncd = 0;
+  auto flush = [&]() { if (ncd) ok(be.copy_batch(cd, ncd)); ncd = 0; };
+  // queue a strided copy (src == nullptr: zero fill); the descriptors between two flushes run as ONE launch and must be
+  // independent of each other
+  auto add = [&](void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+    if (ncd == kCopyBatchMax) flush();
+    if ((dpitch | spitch | width | rows) >> 32) { ok(QVC_ERR_BAD_ARG); return; }
+    cd[ncd++] = CopyDesc{dst, src, (uint32_t)dpitch, (uint32_t)spitch, (uint32_t)width, (uint32_t)rows};
   };
+  // the rings slide at the END of the step, all of them in two launches (out to the scratch, back in: the kept part and
+  // its destination overlap).  A ring is read by exactly one segment per step, so nothing needs it slid earlier.
+  struct Slide { char* ring; size_t rows, keep, hopb; };
+  Slide slides[21];
+  int nslide = 0;
+  auto slide = [&](char* ring, size_t rows, size_t keep, size_t hopb) { slides[nslide++] = Slide{ring, rows, keep, hopb}; };
   auto make = [&](int T, int lag_before) {
     Path<Backend> p{P, blob, ws, carve_workspace(P, B, T), B, T, be};
     p.lens = lens; p.pos = pos; p.off = lag_before + (T - h);      // buffer row `off` is absolute frame pos[b]
     return p;
   };
+  const size_t zrow = (size_t)C * 4;                               // one frame of z
+  const int Tf = 2 * Hf + h;
+  // hand the central hop frames of a segment's result (`src`, frame pitch zrow, `srcT` frames per stream) to coupling
+  // layer k: into its ring's tail AND -- together with the ring's kept part -- into the work copy the layer updates
+  auto feed_flow = [&](int k, const char* src, int srcT) {
+    char* ring = state + S.zf[k];
+    char* zw = ws + X.zwork[k & 1];
+    add(ring + (size_t)2 * Hf * zrow, (size_t)Tf * zrow, src, (size_t)srcT * zrow, (size_t)h * zrow, (size_t)B);
+    add(zw, (size_t)Tf * zrow, ring, (size_t)Tf * zrow, (size_t)2 * Hf * zrow, (size_t)B);
+    add(zw + (size_t)2 * Hf * zrow, (size_t)Tf * zrow, src, (size_t)srcT * zrow, (size_t)h * zrow, (size_t)B);
+    flush();
+  };
 
   {   // the conditioning table (cond rows x g) once per step: every segment's workspace keeps it at the same place
-    Path<Backend> p = make(2 * Hf + h, 0);
+    Path<Backend> p = make(Tf, 0);
     p.cond_table(g);
     ok(p.status);
   }
@@ -147,32 +173,35 @@ int stream_step(const Plan& P, const char* blob, char* state, char* ws, const fl
   {
     const int T = 2 * He + h;
     char* ring = state + S.unit;
-    ok(be.copy2d(ring + (size_t)2 * He * 4, (size_t)T * 4, unit_new, (size_t)h * 4, (size_t)h * 4, (size_t)B * UC));
-    ok(be.zero(ws + X.noise, (size_t)B * C * T * 4));
-    ok(be.copy2d(ws + X.noise + (size_t)He * 4, (size_t)T * 4, noise_new, (size_t)h * 4, (size_t)h * 4, (size_t)B * C));
+    char* nz = ws + X.noise;                                       // zeros either side of the step's noise
+    add(ring + (size_t)2 * He * 4, (size_t)T * 4, unit_new, (size_t)h * 4, (size_t)h * 4, (size_t)B * UC);
+    add(nz, (size_t)T * 4, nullptr, 0, (size_t)He * 4, (size_t)B * C);
+    add(nz + (size_t)He * 4, (size_t)T * 4, noise_new, (size_t)h * 4, (size_t)h * 4, (size_t)B * C);
+    add(nz + (size_t)(He + h) * 4, (size_t)T * 4, nullptr, 0, (size_t)He * 4, (size_t)B * C);
+    flush();
     Path<Backend> p = make(T, 0);
     p.enc_p(reinterpret_cast<const float*>(ring), reinterpret_cast<const float*>(ws + X.noise), p.template wsp<float>(p.W.z));
     ok(p.status);
-    const size_t row = (size_t)C * 4;
-    ok(be.copy2d(state + S.zf[0] + (size_t)2 * Hf * row, (size_t)(2 * Hf + h) * row,
-                 ws + p.W.z + (size_t)He * row, (size_t)T * row, (size_t)h * row, (size_t)B));
+    if (G.nf > 0) feed_flow(0, ws + p.W.z + (size_t)He * zrow, T);
+    else {
+      add(state + S.zd + (size_t)2 * Hd1 * zrow, (size_t)(2 * Hd1 + h) * zrow, ws + p.W.z + (size_t)He * zrow, (size_t)T * zrow, (size_t)h * zrow, (size_t)B);
+      flush();
+    }
     slide(ring, (size_t)B * UC, (size_t)2 * He * 4, (size_t)h * 4);
   }
   // ---- F_k: one coupling layer per segment, in place on a copy of its ring (its edge rows come out wrong and
   //      must not be written back: the ring has to keep the untouched values for the next step's context)
   for (int k = 0; k < G.nf; ++k) {
-    const int T = 2 * Hf + h;
-    const size_t row = (size_t)C * 4, all = (size_t)B * T * row;
-    char* ring = state + S.zf[k];
-    ok(be.copy2d(ws + X.zwork, all, ring, all, all, 1));
-    Path<Backend> p = make(T, He + k * Hf);
-    p.flow_step(P.flow[(size_t)k], reinterpret_cast<float*>(ws + X.zwork), -1.f);
+    char* zw = ws + X.zwork[k & 1];
+    Path<Backend> p = make(Tf, He + k * Hf);
+    p.flow_step(P.flow[(size_t)k], reinterpret_cast<float*>(zw), -1.f);
     ok(p.status);
-    char* next = k + 1 < G.nf ? state + S.zf[k + 1] : state + S.zd;
-    const int nextH = k + 1 < G.nf ? Hf : Hd1;
-    ok(be.copy2d(next + (size_t)2 * nextH * row, (size_t)(2 * nextH + h) * row,
-                 ws + X.zwork + (size_t)Hf * row, (size_t)T * row, (size_t)h * row, (size_t)B));
-    slide(ring, (size_t)B, (size_t)2 * Hf * row, (size_t)h * row);
+    if (k + 1 < G.nf) feed_flow(k + 1, zw + (size_t)Hf * zrow, Tf);
+    else {
+      add(state + S.zd + (size_t)2 * Hd1 * zrow, (size_t)(2 * Hd1 + h) * zrow, zw + (size_t)Hf * zrow, (size_t)Tf * zrow, (size_t)h * zrow, (size_t)B);
+      flush();
+    }
+    slide(state + S.zf[k], (size_t)B, (size_t)2 * Hf * zrow, (size_t)h * zrow);
   }
   // ---- D1: conv_pre + stage 0; its three ResBlock outputs feed the stage-0 rings
   const int ch0 = P.stages[0].ch, r0 = G.r0;
@@ -185,10 +214,11 @@ int stream_step(const Plan& P, const char* blob, char* state, char* ws, const fl
     const size_t row = (size_t)ch0 * 2;
     for (int j = 0; j < 3; ++j) {
       const int jj = j < c.n_resblocks ? j : 0;
-      ok(be.copy2d(state + S.s0[j] + (size_t)2 * Hd2 * r0 * row, (size_t)(2 * Hd2 + h) * r0 * row,
-                   ws + p.W.ra[0][(size_t)jj] + (size_t)Hd1 * r0 * row, (size_t)T * r0 * row, (size_t)h * r0 * row, (size_t)B));
+      add(state + S.s0[j] + (size_t)2 * Hd2 * r0 * row, (size_t)(2 * Hd2 + h) * r0 * row,
+          ws + p.W.ra[0][(size_t)jj] + (size_t)Hd1 * r0 * row, (size_t)T * r0 * row, (size_t)h * r0 * row, (size_t)B);
     }
-    slide(ring, (size_t)B, (size_t)2 * Hd1 * C * 4, (size_t)h * C * 4);
+    flush();
+    slide(ring, (size_t)B, (size_t)2 * Hd1 * zrow, (size_t)h * zrow);
   }
   // ---- D2: remaining stages + conv_post + iSTFT / band synthesis; the central hop frames are the step's output
   {
@@ -198,10 +228,15 @@ int stream_step(const Plan& P, const char* blob, char* state, char* ws, const fl
     for (int j = 0; j < 3; ++j) p.s0_override[j] = state + S.s0[j];
     p.dec_back_wave(p.template wsp<float>(p.W.post), reinterpret_cast<float*>(ws + X.wave));
     ok(p.status);
-    ok(be.copy2d(out, (size_t)h * spf * 4, ws + X.wave + (size_t)Hd2 * spf * 4, (size_t)T * spf * 4, (size_t)h * spf * 4, (size_t)B));
+    add(out, (size_t)h * spf * 4, ws + X.wave + (size_t)Hd2 * spf * 4, (size_t)T * spf * 4, (size_t)h * spf * 4, (size_t)B);
     const size_t row = (size_t)ch0 * 2;
     for (int j = 0; j < 3; ++j) slide(state + S.s0[j], (size_t)B, (size_t)2 * Hd2 * r0 * row, (size_t)h * r0 * row);
   }
+  // ---- slide every ring by one hop: kept parts out (in the launch that also delivers the output), then back in
+  for (int r = 0; r < nslide; ++r) add(ws + X.tmp[r], slides[r].keep, slides[r].ring + slides[r].hopb, slides[r].keep + slides[r].hopb, slides[r].keep, slides[r].rows);
+  flush();
+  for (int r = 0; r < nslide; ++r) add(slides[r].ring, slides[r].keep + slides[r].hopb, ws + X.tmp[r], slides[r].keep, slides[r].keep, slides[r].rows);
+  flush();
   return st;
 }
 
