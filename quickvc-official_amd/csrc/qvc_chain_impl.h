@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NWV * 64) void rbchain_kernel(const ChainArgs A) {
     for (int i = tid; i < 2 * mrg * cpr; i += NTHR) {
       const int r = i / cpr, c8 = i - r * cpr;
       const int row = r < mrg ? r : ROWS + r;
-      *reinterpret_cast<uint4*>(act + row * rowbytes + ((c8 ^ swz(row, sm)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(act + row * rowbytes + ((rotc(c8, sm) ^ swz(row, sm)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
     }
     const int total = ROWS * cpr;
     constexpr int kU = 16;
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(NWV * 64) void rbchain_kernel(const ChainArgs A) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = O::cvt(lrelu((float)h[e], a0.slope));
           }
-          *reinterpret_cast<uint4*>(raw + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = v[u];
-          *reinterpret_cast<frag*>(act + (mrg + r) * rowbytes + ((c8 ^ swz(mrg + r, sm)) << 4)) = o;
+          *reinterpret_cast<uint4*>(raw + r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4)) = v[u];
+          *reinterpret_cast<frag*>(act + (mrg + r) * rowbytes + ((rotc(c8, sm) ^ swz(mrg + r, sm)) << 4)) = o;
         }
         c8 += cstep; r += rstep;
         if (c8 >= cpr) { c8 -= cpr; ++r; }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NWV * 64) void rbchain_kernel(const ChainArgs A) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = (T)0.f;
           }
-          *reinterpret_cast<frag*>(rowp + (((v >> 3) ^ sw) << 4)) = h;
+          *reinterpret_cast<frag*>(rowp + ((rotc(v >> 3, sm) ^ sw) << 4)) = h;
         }
       }
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NWV * 64) void rbchain_kernel(const ChainArgs A) {
         for (int m = 0; m < MF; m += 2) {
           const int v = cb + m * 4;
           if (v >= C) continue;
-          char* rp = raw + r * rowbytes + (((v >> 3) ^ swr) << 4);
+          char* rp = raw + r * rowbytes + ((rotc(v >> 3, sm) ^ swr) << 4);
           sfrag r8 = *reinterpret_cast<const sfrag*>(rp);
           sfrag h;
           h[0] = OS::cvt(acc[m][n][0] + bias[m].x + (float)r8[0]); h[1] = OS::cvt(acc[m][n][1] + bias[m].y + (float)r8[1]);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NWV * 64) void rbchain_kernel(const ChainArgs A) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] = O::cvt(lrelu((float)h[e], a.slope));
             }
-            *reinterpret_cast<frag*>(act + (mrg + r) * rowbytes + (((v >> 3) ^ swa) << 4)) = o;
+            *reinterpret_cast<frag*>(act + (mrg + r) * rowbytes + ((rotc(v >> 3, sm) ^ swa) << 4)) = o;
           }
         }
       }

@@ -24,6 +24,9 @@
 #include "qvc_kernels.h"
 #include "qvc_launch_util.h"
 
+#ifndef QVC_SWZ_ROT
+#define QVC_SWZ_ROT 1                  // 0: the round-1 swizzle of 256-byte-multiple rows (A/B builds of tools/conv_bench)
+#endif
 namespace qvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,14 +81,23 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.f);
 }
 
-// 16-byte-chunk swizzle of a tile row: chunk ^= (row >> sh) & mask, branch-free.  The three modes
-// (mask 15 / 7 for rows of 16k / 8k chunks, (row>>1)&3 otherwise) come from a bank-conflict
-// simulation of the ds_read_b128 lane groups; all are invariant under row += 16.
-struct Swz { int sh, mask; };
+// 16-byte-chunk swizzle of a tile row: chunk' = rotc(chunk) ^ ((row >> sh) & mask), branch-free; all modes are
+// invariant under row += 16.  Rows of 16k chunks (256-byte multiples: every pair / up-sampler / conv_post tile) use
+// rotc = the low four chunk bits rotated right by one, XOR (row & 7): a ds_read_b128 lane group is 8 lanes on chunk c
+// and 8 lanes on chunk c + 1 of eight different rows each (MI355X_MICROARCH.md, LDS), so the chunk's low bit has to
+// pick the 128-byte half and the row's low three bits the slot inside it -- conflict-free for EVERY row offset.
+// The round-1 scheme (chunk ^ (row & 15)) was conflict-free for even offsets only: odd tap shifts (dilations 1, 3, 5
+// x odd taps, almost half of all B reads) were 2-way, 8 LDS cycles instead of 4 (tools/lds_swizzle_sim.py;
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.28 on the pair kernels).  Rows of 8k chunks keep mask 7 (the WaveNet
+// tiles), others (row >> 1) & 3.
+struct Swz { int sh, mask, rot; };
 __device__ __forceinline__ Swz swz_mode(int cpr) {
-  return (cpr & 15) == 0 ? Swz{0, 15} : ((cpr & 7) == 0 ? Swz{0, 7} : Swz{1, 3});
+  return (cpr & 15) == 0 ? Swz{0, QVC_SWZ_ROT ? 7 : 15, QVC_SWZ_ROT} : ((cpr & 7) == 0 ? Swz{0, 7, 0} : Swz{1, 3, 0});
 }
 __device__ __forceinline__ int swz(int row, Swz m) { return (row >> m.sh) & m.mask; }
+__device__ __forceinline__ int rotc(int chunk, Swz m) {
+  return m.rot ? ((chunk & ~15) | ((chunk & 1) << 3) | ((chunk >> 1) & 7)) : chunk;
+}
 
 // leaky ReLU on 8 packed operand values (slope <= 1): max(x, slope*x), in operand arithmetic
 template <typename T>
@@ -178,7 +190,7 @@ __device__ __forceinline__ void gemm_loop_primed(f32x4 (&acc)[MF][NF], typename 
   int tap = 0, ks = 0;                                          // k-step whose B fragments are read next
   auto read_b = [&](frag (&dst)[NF]) {
     const int row0 = tap * dil + colrow;
-    const char* bp = tile + row0 * rowbytes + (((ks * 4 + lq) ^ swz(row0, sm)) << 4);
+    const char* bp = tile + row0 * rowbytes + ((rotc(ks * 4 + lq, sm) ^ swz(row0, sm)) << 4);
 #pragma unroll
     for (int n = 0; n < NF; ++n) dst[n] = *reinterpret_cast<const frag*>(bp + n * nstride);
     if (++ks == KS) { ks = 0; ++tap; }
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           const float4* p = reinterpret_cast<const float4*>(xb + (size_t)src * a.x_ts + c8 * 8);
           v0[u] = p[0]; v1[u] = p[1];
         }
-        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+        dst[u] = idx < total ? r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4) : -1;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           v2[u] = *reinterpret_cast<const uint4*>(xb2 + o);
           v3[u] = *reinterpret_cast<const uint4*>(xb3 + o);
         }
-        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+        dst[u] = idx < total ? r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4) : -1;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const bool ok = idx < total && ti >= Tlo && ti < Tin && (c8 * 8 < a.Cin);
         v[u] = make_uint4(0u, 0u, 0u, 0u);
         if (ok) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)ti * a.x_ts + c8 * 8);
-        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+        dst[u] = idx < total ? r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4) : -1;
       }
 #pragma unroll
       for (int u = 0; u < kU * 2; ++u)
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int ti = t_base + r;
         v[u] = 0.f;
         if (idx < total && c < a.Cin && ti >= Tlo && ti < Tin) v[u] = xb[(size_t)c * a.x_ts + ti];
-        dst[u] = idx < total ? r * rowbytes + (((c >> 3) ^ swz(r, sm)) << 4) + (c & 7) * 2 : -1;
+        dst[u] = idx < total ? r * rowbytes + ((rotc(c >> 3, sm) ^ swz(r, sm)) << 4) + (c & 7) * 2 : -1;
       }
 #pragma unroll
       for (int u = 0; u < kCM; ++u)
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = O::cvt(lrelu((float)h[e], a.slope));
           }
-          *reinterpret_cast<frag*>(smem + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = o;
+          *reinterpret_cast<frag*>(smem + r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4)) = o;
         }
         c8 += cstep; r += rstep;
         if (c8 >= cpr) { c8 -= cpr; ++r; }
@@ -688,7 +700,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = (T)0.f;
           }
-          *reinterpret_cast<frag*>(rowp + (((v >> 3) ^ sw) << 4)) = h;
+          *reinterpret_cast<frag*>(rowp + ((rotc(v >> 3, sm) ^ sw) << 4)) = h;
         }
       } else {
 #pragma unroll
@@ -702,7 +714,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
           } else {
             h[0] = h[1] = h[2] = h[3] = (T)0.f;
           }
-          *reinterpret_cast<quad*>(rowp + (((v >> 3) ^ sw) << 4) + (v & 7) * 2) = h;
+          *reinterpret_cast<quad*>(rowp + ((rotc(v >> 3, sm) ^ sw) << 4) + (v & 7) * 2) = h;
         }
       }
     }
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
           const float4* p = reinterpret_cast<const float4*>(xb + (size_t)ti * a.H + c8 * 8);
           v0[u] = p[0]; v1[u] = p[1];
         }
-        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+        dst[u] = idx < total ? r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4) : -1;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -876,7 +888,7 @@ __global__ __launch_bounds__(WV * 64) void wn_layer_kernel(const WnArgs a) {
         } else {
           o[0] = o[1] = o[2] = o[3] = (T)0.f;                    // K padding of the 1x1 must be finite
         }
-        *reinterpret_cast<quad*>(acts + j * rowbytes + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
+        *reinterpret_cast<quad*>(acts + j * rowbytes + ((rotc(ch0 >> 3, sm) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
       }
     }
   }
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         frag h;
         h[0] = O::cvt(v0.x); h[1] = O::cvt(v0.y); h[2] = O::cvt(v0.z); h[3] = O::cvt(v0.w);
         h[4] = O::cvt(v1.x); h[5] = O::cvt(v1.y); h[6] = O::cvt(v1.z); h[7] = O::cvt(v1.w);
-        *reinterpret_cast<frag*>(acts + r * rowbytes + ((c8 ^ swz(r, sm)) << 4)) = h;
+        *reinterpret_cast<frag*>(acts + r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4)) = h;
       }
     }
     __syncthreads();
@@ -1053,7 +1065,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
         const int r = n * 16 + lrow + left;
         quad h;
         h[0] = O::cvt(xr[f][n][0]); h[1] = O::cvt(xr[f][n][1]); h[2] = O::cvt(xr[f][n][2]); h[3] = O::cvt(xr[f][n][3]);
-        *reinterpret_cast<quad*>(smem + r * rowbytes + (((ch0 >> 3) ^ swz(r, sm)) << 4) + (ch0 & 7) * 2) = h;
+        *reinterpret_cast<quad*>(smem + r * rowbytes + ((rotc(ch0 >> 3, sm) ^ swz(r, sm)) << 4) + (ch0 & 7) * 2) = h;
       }
     }
   };
@@ -1096,7 +1108,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
           } else {
             o[0] = o[1] = o[2] = o[3] = (T)0.f;
           }
-          *reinterpret_cast<quad*>(acts + j * rowbytes + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
+          *reinterpret_cast<quad*>(acts + j * rowbytes + ((rotc(ch0 >> 3, sm) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
         }
       }
     }
@@ -1187,7 +1199,7 @@ __global__ __launch_bounds__(WV * 64) void wn_stack_kernel(const WnStackArgs a) 
           } else {
             h[0] = h[1] = h[2] = h[3] = (T)0.f;
           }
-          *reinterpret_cast<quad*>(acts + j * rowbytes + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = h;
+          *reinterpret_cast<quad*>(acts + j * rowbytes + ((rotc(ch0 >> 3, sm) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = h;
         }
       }
       __syncthreads();

@@ -112,7 +112,7 @@ void post_tail_kernel(const PostTailArgs A) {
           v2[u] = *reinterpret_cast<const uint4*>(xb2 + o);
           v3[u] = *reinterpret_cast<const uint4*>(xb3 + o);
         }
-        dst[u] = idx < total ? r * rowbytes + ((c8 ^ swz(r, sm)) << 4) : -1;
+        dst[u] = idx < total ? r * rowbytes + ((rotc(c8, sm) ^ swz(r, sm)) << 4) : -1;
         r += rstep;
       }
 #pragma unroll

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
   // fp32 residual stream and skip sum of the window: lane-private 16-byte slots in LDS ([n][thread]), touched only in a
   // layer's epilogue -- in registers (24 per lane) they pushed the K loops' ring into scratch memory
   constexpr int XRES = ACTS + NB * RB, OACC = XRES + NF * NTH * 16;
-  const Swz sm{0, 7};
+  const Swz sm{0, 7, 0};
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
         frag h;
         h[0] = O::cvt(v0.x); h[1] = O::cvt(v0.y); h[2] = O::cvt(v0.z); h[3] = O::cvt(v0.w);
         h[4] = O::cvt(v1.x); h[5] = O::cvt(v1.y); h[6] = O::cvt(v1.z); h[7] = O::cvt(v1.w);
-        *reinterpret_cast<frag*>(acts + r * RB + ((c8 ^ swz(r, sm)) << 4)) = h;
+        *reinterpret_cast<frag*>(acts + r * RB + ((rotc(c8, sm) ^ swz(r, sm)) << 4)) = h;
       }
     }
     __syncthreads();
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
         } else {
           o[0] = o[1] = o[2] = o[3] = (T)0.f;
         }
-        *reinterpret_cast<quad*>(acts + j * RB + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
+        *reinterpret_cast<quad*>(acts + j * RB + ((rotc(ch0 >> 3, sm) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = o;
       }
     }
     // res / skip biases: requested before the barrier, used after GEMM2
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(KS * 2 * 64) void wn_stack2_kernel(const WnStackArg
         } else {
           h[0] = h[1] = h[2] = h[3] = (T)0.f;
         }
-        *reinterpret_cast<quad*>(acts + j * RB + (((ch0 >> 3) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = h;
+        *reinterpret_cast<quad*>(acts + j * RB + ((rotc(ch0 >> 3, sm) ^ swz(j, sm)) << 4) + (ch0 & 7) * 2) = h;
       }
       __syncthreads();
       f32x4 qacc[PM][ON];
