@@ -21,6 +21,9 @@
  *   - all device work is enqueued asynchronously on the caller's hipStream_t
  *     (passed as void*); no host sync, no allocation, no host read inside, so
  *     every call is hipGraph-capturable.  Thread-safe by statelessness.
+ *     Calls on DIFFERENT streams may overlap as long as each has its own workspace, state
+ *     and output buffers (the packed weights are read-only and may be shared): bench.py
+ *     and convert.py keep two batches in flight that way.
  *   - every entry point that needs scratch has a *_workspace_bytes() query.
  *
  * Layouts
