@@ -86,6 +86,9 @@ def main() -> None:
                     help="batches in flight per GPU: step i runs on lane i %% N, each lane with its own inputs, workspace, output, "
                          "hipGraph and HIP stream, so the next batch fills the launch tails and dependency gaps of the current "
                          "one (results are bit-identical to one lane; 1 = strictly one batch at a time)")
+    ap.add_argument("--settle", type=int, default=40, metavar="S",
+                    help="untimed steps at the end of the set-up, before the W warm-up steps, so the device is at its steady clock "
+                         "whatever W is (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--branches", action="store_true", help="run the three ResBlocks of a stage as parallel graph branches (only stages whose pairs do NOT run fused take that path)")
@@ -188,6 +191,12 @@ def main() -> None:
             else:
                 engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])
 
+    # Part of the set-up, not of the W warm-up steps: building the lanes (allocation, capture) leaves the device idle long
+    # enough for its clock to drop, and it needs ~20 steps (~45 ms) to come back (tools/warmup_probe.py).  Without this the
+    # K timed steps after a handful of warm-up steps measure that ramp (1.88 vs 1.82 ms); `steady_state` below stays as
+    # the cross-check.
+    for _ in range(args.settle):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -202,9 +211,9 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    # The device needs ~20 steps (~45 ms) after idle to reach its steady clock (tools/warmup_probe.py: 2.24, 2.50,
-    # 2.35, 2.25, 2.16 ... -> 1.98 ms per step), so with a handful of warm-up steps `value` above still contains
-    # part of that ramp.  A second window of K steps, 40 steps later, is reported next to it as `steady_state`.
+    # A second window of K steps, 40 steps later, is reported next to `value` as `steady_state`: the two agree when the
+    # settle steps above did their job (with --settle 0 `value` contains the clock ramp: 2.24, 2.50, 2.35, 2.25, 2.16 ...
+    # -> 1.98 ms per step, tools/warmup_probe.py).
     for _ in range(40):
         step()
     torch.cuda.synchronize()
@@ -240,7 +249,7 @@ def main() -> None:
 
     steady = {"ms_per_step": wall_steady / args.steps * 1e3, "value": samples_per_step * args.steps / wall_steady,
               "note": f"the same {args.steps} steps timed again after 40 more steps (device at its steady clock); "
-                      "`value` is the first window, right after the warm-up steps"}
+                      "`value` is the first window, right after the settle + warm-up steps"}
     result = {
         "metric": "audio samples/sec (16 kHz, 5 s utterances, batch 32 per GPU, whole hot path)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -255,7 +264,7 @@ def main() -> None:
                    "batches_in_flight": n_lanes,
                    **({"debug_switches": args.debug} if args.debug else {})},
         "rtf": wall / args.steps / (world * B * FRAMES * engine.samples_per_frame / SAMPLE_RATE),
-        "steady_state": steady,
+        "steady_state": steady, "settle_steps": args.settle,
         "one_batch_at_a_time": {"ms_per_step": wall_single / args.steps * 1e3, "value": samples_per_step * args.steps / wall_single,
                                 "note": "the same graphs replayed on one lane only (steady clock); the per-launch durations of the "
                                         "roofline leg and of the rocprofv3 summary are taken in this mode",
