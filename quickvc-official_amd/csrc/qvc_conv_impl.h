@@ -623,6 +623,10 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   const int Tb = ragged_len(A.rg, b, a.T);     // this utterance occupies rows [Tlo, Tb): both convs zero-pad at ITS ends
   const int Tlo = ragged_lo(A.rg, b);
   if (q0 >= Tb) return;                        // tile past the end of the utterance (ragged batches)
+#ifdef QVC_STAMP
+  unsigned long long* st_ = A.stamps ? A.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8 : nullptr;
+#endif
+  QVC_ST(0);
 
   if (!QVC_ABL(0)) {   // ---- stage lrelu(x): every load of the tile is in flight before the first conversion
     // (no accumulator is live yet, so the registers are free: one memory round trip per tile instead of two)
@@ -665,6 +669,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
     }
   }
   __syncthreads();
+  QVC_ST(1);
 
   {   // ---- GEMM1 over N1P frames, then bias + lrelu -> intermediate tile (in place of the input tile)
     f32x4 acc[MF][NF1];
@@ -674,10 +679,12 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
       for (int n = 0; n < NF1; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w1) + ((size_t)wm * a.nIt * MF) * 64 + lane;
     if (!QVC_ABL(1)) gemm_loop<T, MF, NF1, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, a.dil, smem, rowbytes, sm, wn * (NF1 * 16) + lrow, lq, QVC_ROT(a.nIt));
+    QVC_ST(2);
     float4 bias[MF];                     // the bias array is padded to WM*MF*16 entries (zeros past C)
 #pragma unroll
     for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b1 + cb + m * 4);
     __syncthreads();                     // every wave is done reading the input tile
+    QVC_ST(3);
 #pragma unroll
     for (int n = 0; n < NF1; ++n) {
       const int jr = wn * (NF1 * 16) + n * 16 + lrow;            // intermediate row <-> frame q0 - h2 + jr
@@ -720,6 +727,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
     }
   }
   __syncthreads();
+  QVC_ST(4);
 
   {   // ---- GEMM2 over NT frames (dilation 1) + bias + residual
     f32x4 acc[MF][NF];
@@ -729,6 +737,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
       for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const frag* ap = static_cast<const frag*>(a.w2) + ((size_t)wm * a.nIt * MF) * 64 + lane;
     if (!QVC_ABL(2)) gemm_loop<T, MF, NF, QVC_PF_CONV>(acc, ap, a.nIt, a.KS, 1, smem, rowbytes, sm, wn * (NF * 16) + lrow, lq, QVC_ROT(a.nIt));
+    QVC_ST(5);
     float4 bias[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m) bias[m] = *reinterpret_cast<const float4*>(a.b2 + cb + m * 4);
@@ -795,6 +804,10 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         }
       }
     }
+#ifdef QVC_STAMP
+    __builtin_amdgcn_s_waitcnt(0);         // the stores have left the wave's queue (vmcnt covers stores on this target)
+#endif
+    QVC_ST(6);
   }
 }
 

@@ -106,6 +106,9 @@ struct PairArgs3 {
   //    chain's -- the one-workgroup-per-CU layouts, where the launch then behaves like n launches back to back without
   //    the gaps between them; 0: chain = blockIdx.x % n (chains interleaved on the CUs)
   int32_t chain_major = 0;
+#ifdef QVC_STAMP
+  unsigned long long* stamps = nullptr;   // developer build only (tools/conv_bench): [workgroup][8 waves][8] phase stamps
+#endif
 };
 
 // A whole ResBlock1 -- n chained pairs (dilations d_0 .. d_{n-1}) -- in ONE launch (qvc_chain_impl.h), for chains whose

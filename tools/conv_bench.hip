@@ -275,6 +275,37 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("pair3 %s d%d  %-12s NF%-3d %8.1f us  %7.1f TF\n", sg.name, dils[q], cm ? "chain-major" : "interleaved", nf, ms * 1e3 / reps, tot_fl / (ms * 1e3 / reps) * 1e-6);
+#ifdef QVC_STAMP
+        if (cm == 1 && q == 0) {   // phase stamps of one chain-major launch (s_memtime cycles), wave 0 of every workgroup
+          const int NT = nf * 16 * (d1s[0].WM == block_waves(d1s[0]) ? 1 : block_waves(d1s[0]) / d1s[0].WM);
+          const int tiles = ceil_div(sg.T, NT);
+          const size_t nwg = (size_t)tiles * B * 3;
+          unsigned long long* dst; CK(hipMalloc(&dst, nwg * 64 * 8)); CK(hipMemset(dst, 0, nwg * 64 * 8));
+          a3.stamps = dst;
+          launch_pair3(d1s, d2s, a3, B, QVC_F16, st, &nf);
+          CK(hipStreamSynchronize(st));
+          a3.stamps = nullptr;
+          std::vector<unsigned long long> hs(nwg * 64);
+          CK(hipMemcpy(hs.data(), dst, nwg * 64 * 8, hipMemcpyDeviceToHost));
+          CK(hipFree(dst));
+          unsigned long long t0 = ~0ull, t1 = 0;
+          for (size_t w = 0; w < nwg; ++w) if (hs[w * 64]) { t0 = std::min(t0, hs[w * 64]); t1 = std::max(t1, hs[w * 64 + 6]); }
+          static const char* ph[6] = {"stage", "gemm1", "bar", "write", "gemm2", "epilogue"};
+          for (int c = 0; c < 3; ++c) {
+            double sum[6] = {0, 0, 0, 0, 0, 0}, tot = 0, start = 0; size_t cnt = 0;
+            for (size_t w = (size_t)c * tiles * B; w < (size_t)(c + 1) * tiles * B; ++w) {
+              const unsigned long long* s8 = &hs[w * 64];
+              if (!s8[0] || !s8[6]) continue;
+              for (int p = 0; p < 6; ++p) sum[p] += (double)(s8[p + 1] - s8[p]);
+              tot += (double)(s8[6] - s8[0]); start += (double)(s8[0] - t0); ++cnt;
+            }
+            printf("stamps %s k%-2d: %zu workgroups, mean %.0f cycles |", sg.name, ks[c], cnt, tot / cnt);
+            for (int p = 0; p < 6; ++p) printf(" %s %.0f", ph[p], sum[p] / cnt);
+            printf(" | mean start %.0f\n", start / cnt);
+          }
+          printf("stamps %s: launch span %llu cycles\n", sg.name, t1 - t0);
+        }
+#endif
       }
       printf("pair3 %s d%d  three launches %8.1f us  %7.1f TF\n", sg.name, dils[q], tot_us, tot_fl / tot_us * 1e-6);
       for (int c = 0; c < 3; ++c) CK(hipFree(dws[c]));
