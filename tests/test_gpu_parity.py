@@ -646,6 +646,26 @@ def test_incremental_streaming_at_stated_size(lib, dev, hop, T):
     assert snr_db(whole.cpu(), streamed.cpu()) >= 90.0
 
 
+def test_incremental_streaming_odd_hop(lib, dev):
+    """A hop that is not a multiple of four frames (7): the step's batched copies (copy_batch_kernel) then move rows whose
+    byte widths / pitches are not multiples of 16 and fall back to 4-byte elements for those descriptors.  3 streams, no
+    graph, streamed == whole utterance."""
+    from quickvc_official_amd.streaming import StreamConverter
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    model, sd, _u, _g, _n = regenerate(entry)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    S, T, hop = 3, 121, 7
+    unit, g, noise = make_synthetic_inputs(S, T, 256, 192, 256, seed0=6400)
+    conv = StreamConverter(model, streams=S, hop_frames=hop, use_graph=False)
+    streamed = conv.convert(unit.cuda(), g.cuda(), noise.cuda())
+    whole = model.infer_batch(unit.cuda(), g.cuda(), noise.cuda())
+    torch.cuda.synchronize()
+    assert streamed.shape == whole.shape == (S, 1, 320 * T) and bool(torch.isfinite(streamed).all())
+    assert min(snr_db(whole[s].cpu(), streamed[s].cpu()) for s in range(S)) >= 90.0
+
+
 def test_streams_of_different_lengths_in_the_mixed_operand_mode(lib, dev):
     """Streams that end at different frames, `bf16x` operands, hop 40: every stream's concatenated step outputs
     equal that stream converted alone through the offline path in the same operand mode (the stream ends inside a
