@@ -624,7 +624,8 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   const int Tlo = ragged_lo(A.rg, b);
   if (q0 >= Tb) return;                        // tile past the end of the utterance (ragged batches)
 #ifdef QVC_STAMP
-  unsigned long long* st_ = A.stamps ? A.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8 : nullptr;
+  // wave 0 of every workgroup: 64 slots; 0-6 the phases, 8 = tile loads issued, 9 = first data back, 10 = converted and written
+  unsigned long long* st_ = (A.stamps && wave == 0) ? A.stamps + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 : nullptr;
 #endif
   QVC_ST(0);
 
@@ -648,6 +649,13 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
         if (c8 >= cpr) { c8 -= cpr; ++r; }
       }
       r = r_0; c8 = c_0;
+#ifdef QVC_STAMP
+      if (base == tid) {
+        QVC_ST(8);
+        asm volatile("s_waitcnt vmcnt(15)" ::: "memory");      // the first of the 16 loads is back
+        QVC_ST(9);
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int idx = base + u * NTHR;
@@ -668,6 +676,7 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
       }
     }
   }
+  QVC_ST(10);
   __syncthreads();
   QVC_ST(1);
 

@@ -107,7 +107,7 @@ struct PairArgs3 {
   //    the gaps between them; 0: chain = blockIdx.x % n (chains interleaved on the CUs)
   int32_t chain_major = 0;
 #ifdef QVC_STAMP
-  unsigned long long* stamps = nullptr;   // developer build only (tools/conv_bench): [workgroup][8 waves][8] phase stamps
+  unsigned long long* stamps = nullptr;   // developer build only (tools/conv_bench): [workgroup][64] phase stamps of wave 0
 #endif
 };
 

@@ -301,7 +301,14 @@ int main(int argc, char** argv) {
             }
             printf("stamps %s k%-2d: %zu workgroups, mean %.0f cycles |", sg.name, ks[c], cnt, tot / cnt);
             for (int p = 0; p < 6; ++p) printf(" %s %.0f", ph[p], sum[p] / cnt);
-            printf(" | mean start %.0f\n", start / cnt);
+            double i8 = 0, i9 = 0, i10 = 0;
+            for (size_t w = (size_t)c * tiles * B; w < (size_t)(c + 1) * tiles * B; ++w) {
+              const unsigned long long* s8 = &hs[w * 64];
+              if (!s8[0] || !s8[6] || !s8[8]) continue;
+              i8 += (double)(s8[8] - s8[0]); i9 += (double)(s8[9] - s8[8]); i10 += (double)(s8[10] - s8[9]);
+            }
+            printf(" | inside stage: loads issued %.0f, first data +%.0f, converted + written +%.0f, barrier +%.0f\n", i8 / cnt, i9 / cnt, i10 / cnt,
+                   (sum[0] - i8 - i9 - i10) / cnt);
           }
           printf("stamps %s: launch span %llu cycles\n", sg.name, t1 - t0);
         }
