@@ -143,14 +143,7 @@ def main() -> None:
     # ---- one step = one batch through the hot path, optionally as a hipGraph (the library call is capturable: no
     #      sync/alloc inside).  A lane owns everything a batch touches -- inputs, workspace (the graph bakes its pointer
     #      in), output, graph, stream -- so consecutive steps on different lanes are independent and may overlap.
-    lanes = []
-    agg, reps, total_ms = {}, 5, 0.0
-    for k in range(n_lanes):
-        if k == 1 and rank == 0:
-            # ---- roofline leg, BEFORE a second lane exists: per-launch HIP events on lane 0's stream, same workload, chip
-            #      at its steady clock.  (Taken after the two-lane windows the very same eager launches measured 10 % longer
-            #      -- 249 vs 225 us for the dominant kernel, rocprofv3 of the one-lane run: 225 us.)
-            roofline_leg()
+    def make_lane(k: int) -> dict:
         u_k, g_k, n_k = make_synthetic_inputs(B, FRAMES, 256, cfg["inter_channels"], cfg["gin_channels"], seed0=(rank + world * k) * B)
         lane = {"unit": u_k.to(device), "g": g_k.to(device), "noise": n_k.to(device), "stream": torch.cuda.Stream(device), "graph": None,
                 "out": torch.empty(B, 1, FRAMES * engine.samples_per_frame, dtype=torch.float32, device=device),
@@ -162,37 +155,41 @@ def main() -> None:
                 lane["graph"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(lane["graph"], stream=lane["stream"]):
                     engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])
-        lanes.append(lane)
-        if k == 0:
-            unit, g, noise, out, stream, graph = (lane[key] for key in ("unit", "g", "noise", "out", "stream", "graph"))
+        return lane
 
-            def roofline_leg():
-                nonlocal total_ms
-                with torch.cuda.stream(stream):
-                    for _ in range(25):                     # the clock ramp (tools/warmup_probe.py)
-                        (graph.replay() if graph is not None else engine.infer_batch(unit, g, noise, out, ws=lanes[0]["ws"]))
-                    # 9 repetitions, the 5 with the smallest step total are kept: one disturbed repetition (seen once on
-                    # a pool box: the stage-1 pairs 37 % slower for a moment) would otherwise name the wrong dominant kernel
-                    runs = [engine.infer_batch_timed(unit, g, noise, out)[1] for _ in range(reps + 4)]
-                    runs.sort(key=lambda recs: sum(r["ms"] for r in recs))
-                    for recs in runs[:reps]:
-                        for r in recs:
-                            a = agg.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-                            a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
-                            total_ms += r["ms"]
-                torch.cuda.synchronize()
-    if n_lanes == 1 and rank == 0:
-        roofline_leg()
-    step_no = [0]
-
-    def step(in_flight=n_lanes):
-        lane = lanes[step_no[0] % in_flight]
-        step_no[0] += 1
+    def run_lane(lane: dict) -> None:
         with torch.cuda.stream(lane["stream"]):
             if lane["graph"] is not None:
                 lane["graph"].replay()
             else:
                 engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])
+
+    lanes = [make_lane(0)]
+    unit, g, noise, out, stream, graph = (lanes[0][key] for key in ("unit", "g", "noise", "out", "stream", "graph"))
+    agg, reps, total_ms = {}, 5, 0.0
+    if rank == 0:
+        # ---- roofline leg, BEFORE a second lane exists: per-launch HIP events on lane 0's stream (qvc_infer_batch_timed),
+        #      same workload, chip at its steady clock.  (Taken after the two-lane windows the very same eager launches
+        #      measured 10 % longer -- 249 vs 225 us for the dominant kernel, rocprofv3 of the one-lane run: 225 us.)
+        for _ in range(25):                                 # the clock ramp (tools/warmup_probe.py)
+            run_lane(lanes[0])
+        with torch.cuda.stream(stream):
+            # 9 repetitions, the 5 with the smallest step total are kept: one disturbed repetition (seen once on a pool
+            # box: the stage-1 pairs 37 % slower for a moment) would otherwise name the wrong dominant kernel
+            runs = [engine.infer_batch_timed(unit, g, noise, out)[1] for _ in range(reps + 4)]
+        runs.sort(key=lambda recs: sum(r["ms"] for r in recs))
+        for recs in runs[:reps]:
+            for r in recs:
+                a = agg.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
+                total_ms += r["ms"]
+        torch.cuda.synchronize()
+    lanes += [make_lane(k) for k in range(1, n_lanes)]
+    step_no = [0]
+
+    def step(in_flight=n_lanes):
+        run_lane(lanes[step_no[0] % in_flight])
+        step_no[0] += 1
 
     # Part of the set-up, not of the W warm-up steps: building the lanes (allocation, capture) leaves the device idle long
     # enough for its clock to drop, and it needs ~20 steps (~45 ms) to come back (tools/warmup_probe.py).  Without this the
@@ -238,9 +235,7 @@ def main() -> None:
         # overlap must not change a single bit: every lane's output against the same graph run alone
         for lane in lanes:
             before = lane["out"].clone()
-            with torch.cuda.stream(lane["stream"]):
-                (lane["graph"].replay() if lane["graph"] is not None else
-                 engine.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"]))
+            run_lane(lane)
             torch.cuda.synchronize()
             lanes_identical = lanes_identical and bool(torch.equal(before, lane["out"]))
     wall = qd.max_over_ranks(wall, device)
