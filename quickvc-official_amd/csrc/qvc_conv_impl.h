@@ -628,6 +628,9 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
   unsigned long long* st_ = (A.stamps && wave == 0) ? A.stamps + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 : nullptr;
 #endif
   QVC_ST(0);
+#ifdef QVC_STAMP
+  if (st_ && lane == 0) st_[11] = __builtin_amdgcn_s_memrealtime();      // 100 MHz: with slots 0 / 6 the clock the chip holds
+#endif
 
   if (!QVC_ABL(0)) {   // ---- stage lrelu(x): every load of the tile is in flight before the first conversion
     // (no accumulator is live yet, so the registers are free: one memory round trip per tile instead of two)
@@ -817,6 +820,9 @@ __global__ __launch_bounds__(NWV * 64) void rbpair_kernel(const PairArgs3 A) {
     __builtin_amdgcn_s_waitcnt(0);         // the stores have left the wave's queue (vmcnt covers stores on this target)
 #endif
     QVC_ST(6);
+#ifdef QVC_STAMP
+    if (st_ && lane == 0) st_[12] = __builtin_amdgcn_s_memrealtime();
+#endif
   }
 }
 

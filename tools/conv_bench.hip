@@ -307,6 +307,15 @@ int main(int argc, char** argv) {
               if (!s8[0] || !s8[6] || !s8[8]) continue;
               i8 += (double)(s8[8] - s8[0]); i9 += (double)(s8[9] - s8[8]); i10 += (double)(s8[10] - s8[9]);
             }
+            {
+              double cyc = 0, rt = 0;
+              for (size_t w = (size_t)c * tiles * B; w < (size_t)(c + 1) * tiles * B; ++w) {
+                const unsigned long long* s8 = &hs[w * 64];
+                if (!s8[0] || !s8[6] || !s8[12]) continue;
+                cyc += (double)(s8[6] - s8[0]); rt += (double)(s8[12] - s8[11]);
+              }
+              printf(" | clock %.2f GHz", rt > 0 ? cyc / rt * 0.1 : 0.0);
+            }
             printf(" | inside stage: loads issued %.0f, first data +%.0f, converted + written +%.0f, barrier +%.0f\n", i8 / cnt, i9 / cnt, i10 / cnt,
                    (sum[0] - i8 - i9 - i10) / cnt);
           }
