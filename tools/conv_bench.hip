@@ -20,6 +20,9 @@ int main(int argc, char** argv) {
   // QVC_BENCH_ZEROS=1: all-zero activations and weights -- same instruction stream and cycles, but the chip holds a
   // higher clock on zero operands (DVFS), so the ratio to the random-data run is the clock given back under load
   const bool zeros = getenv("QVC_BENCH_ZEROS") != nullptr;
+  // QVC_BENCH_PAIRS / QVC_BENCH_WN: only the ResBlock pairs / only the WaveNet stack launches (e.g. with many repetitions
+  // under tools/power_probe.sh, to see what one kernel family draws)
+  const bool only_pairs = getenv("QVC_BENCH_PAIRS") != nullptr, only_wn = getenv("QVC_BENCH_WN") != nullptr;
   std::vector<Shape> shapes = {
     {"s2 c1 k3 d1", 128, 128, 5000, 3, 1, 0}, {"s2 c1 k7 d3", 128, 128, 5000, 7, 3, 0}, {"s2 c1 k11 d5", 128, 128, 5000, 11, 5, 0},
     {"s2 c2 k3", 128, 128, 5000, 3, 1, 1}, {"s2 c2 k11", 128, 128, 5000, 11, 1, 1},
@@ -43,7 +46,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(bb, 0, 1 << 20));
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  if (!getenv("QVC_BENCH_PAIRS")) for (const Shape& s : shapes) {
+  if (!only_pairs && !only_wn) for (const Shape& s : shapes) {
     ConvDesc d = make_conv(s.M, s.Cin, s.k, s.dil, s.kind == 2);
     d.w_off = 0; d.b_off = align_up(d.w_bytes(), 256);
     size_t wb = d.b_off + d.b_bytes();
@@ -73,7 +76,7 @@ int main(int argc, char** argv) {
     printf("%-14s MF%d WM%d NF%-2d chunks%d  %8.1f us  %7.1f TF  (%.1f%% of 2.5PF)\n", s.name, d.MF, d.WM, nf, d.nchunk, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
-  if (!getenv("QVC_BENCH_PAIRS")) {  // ---- polyphase up-samplers, conv_pre (weight-heavy, few frames)
+  if (!only_pairs && !only_wn) {  // ---- polyphase up-samplers, conv_pre (weight-heavy, few frames)
     struct U { const char* name; int Cin, Cout, T, k, s, p; int kind; };
     std::vector<U> us = {{"ups0 512>256 s5", 512, 256, 250, 16, 5, 6, 0}, {"ups1 256>128 s4", 256, 128, 1250, 16, 4, 6, 1}};
     for (const U& u : us) {
@@ -108,7 +111,7 @@ int main(int argc, char** argv) {
       CK(hipFree(dw));
     }
   }
-  if (!getenv("QVC_BENCH_PAIRS")) {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
+  if (!only_pairs && !only_wn) {  // ---- fused WaveNet layers: 16 distinct weight sets in sequence (cold weights, as in the real step)
     const int H = 192, T = 250, L = 16;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
     wn_layout(din, 2); wn_layout(drs, 2);
@@ -134,7 +137,7 @@ int main(int argc, char** argv) {
     printf("%-14s W%-2d NF%-2d               %8.1f us/layer  %7.1f TF  (%.1f%% of 2.5PF)\n", "wn layer x16", din.WM, nf, us, flops / us * 1e-6, flops / us * 1e-6 / 25.0);
     CK(hipFree(dw));
   }
-  if (!getenv("QVC_BENCH_PAIRS")) {  // ---- whole-stack WaveNet launches: 4 layers per launch, 8 distinct weight sets (cold weights)
+  if (!only_pairs) {  // ---- whole-stack WaveNet launches: 4 layers per launch, 8 distinct weight sets (cold weights)
     const int H = 192, T = 250, L = 4, SETS = 8;
     ConvDesc din = make_conv(2 * H, H, 5, 1, true), drs = make_conv(2 * H, H, 1, 1, true);
     wn_layout(din, 2); wn_layout(drs, 2);
@@ -228,7 +231,7 @@ int main(int argc, char** argv) {
   }
   // ---- fused ResBlock pairs: one launch per chain, and pair q of the three chains (k 3 / 7 / 11) as ONE launch
   struct Stage { const char* name; int C, T; };
-  for (const Stage& sg : {Stage{"s2", 128, 5000}, Stage{"s1", 256, 1250}}) {
+  if (!only_wn) for (const Stage& sg : {Stage{"s2", 128, 5000}, Stage{"s1", 256, 1250}}) {
     const int ks[3] = {11, 7, 3}, dils[3] = {1, 3, 5};
     for (int q = 0; q < 3; ++q) {
       ConvDesc d1s[3], d2s[3]; PairArgs3 a3; a3.n = 3;
