@@ -531,6 +531,40 @@ def test_hipgraph_capture_replays_identically(lib, dev):
     assert torch.equal(out, eager)
 
 
+def test_two_batches_in_flight_are_bit_identical(lib, dev):
+    """The library keeps no state between calls: two batches on two HIP streams, each with its own workspace, output and
+    hipGraph (what bench.py --in-flight 2 and the corpus pipeline's lanes do), overlap on the device and still give
+    exactly what each gives alone.  Shipped config, batch 8 x 100 frames, the two lanes replayed alternately."""
+    from quickvc_official_amd.synth import make_synthetic_inputs
+    entry, _ = load_case("full_b1")
+    _m, sd, _u, _g, _n = regenerate(entry)
+    eng = _engine(entry, sd, dev, "bf16x")
+    B, T = 8, 100
+    lanes = []
+    for k in range(2):
+        unit, g, noise = make_synthetic_inputs(B, T, 256, 192, 256, seed0=8800 + 100 * k)
+        lane = dict(unit=unit.to(dev), g=g.to(dev), noise=noise.to(dev), ws=eng.alloc_workspace(B, T),
+                    out=torch.empty(B, 1, 320 * T, device=dev), stream=torch.cuda.Stream(dev), graph=torch.cuda.CUDAGraph())
+        with torch.cuda.stream(lane["stream"]):
+            lane["alone"] = eng.infer_batch(lane["unit"], lane["g"], lane["noise"], ws=lane["ws"]).clone()
+            lane["stream"].synchronize()
+            with torch.cuda.graph(lane["graph"], stream=lane["stream"]):
+                eng.infer_batch(lane["unit"], lane["g"], lane["noise"], lane["out"], ws=lane["ws"])
+        lanes.append(lane)
+    torch.cuda.synchronize()
+    for lane in lanes:
+        lane["out"].zero_()
+    torch.cuda.synchronize()
+    for _ in range(6):
+        for lane in lanes:
+            with torch.cuda.stream(lane["stream"]):
+                lane["graph"].replay()
+    torch.cuda.synchronize()
+    for lane in lanes:
+        assert torch.equal(lane["out"], lane["alone"])
+    assert not torch.equal(lanes[0]["out"], lanes[1]["out"])
+
+
 def test_timed_variant_reports_every_launch(lib, dev):
     entry, _ = load_case("mini")
     _m, sd, unit, g, noise = regenerate(entry)
